@@ -1,0 +1,255 @@
+/*
+ * sg3_ops.h -- C ABI of libsg3hip.so, the MI355X (gfx950) replacement for the
+ * native plugins behind krylea/stylegan3-editing's `torch_utils.ops` package.
+ *
+ * Boundary rules (all entry points):
+ *   - plain C: raw device pointers, sizes, strides; no torch / C++ types.
+ *   - the CALLER owns and allocates every buffer (inputs, outputs, sign
+ *     tensors) and computes their sizes with the sg3_*_shape helpers below
+ *     (host-only, no GPU needed);
+ *   - every launch is asynchronous on the `hipStream_t` passed as `void*
+ *     stream` (NULL = the null stream); no call synchronises, allocates or
+ *     keeps state between calls, so concurrent streams are safe (the
+ *     reference keeps its taps in one global __constant__ buffer and is not:
+ *     reference torch_utils/ops/filtered_lrelu.py:216-217);
+ *   - return value: SG3_OK (0) on success, SG3_NO_KERNEL (-1) when no
+ *     specialised kernel exists for the (up, down, taps) tuple -- the same
+ *     meaning as the reference's rc (reference torch_utils/ops/
+ *     filtered_lrelu.cpp:52-56) -- and < -1 for an invalid argument or a HIP
+ *     launch error; sg3_last_error() returns a thread-local message.
+ *
+ * Each function cites the reference interface it replaces (paths relative to
+ * the reference tree).
+ */
+#ifndef SG3_OPS_H
+#define SG3_OPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG3_ABI_VERSION 1
+
+enum {
+    SG3_OK          =  0,
+    SG3_NO_KERNEL   = -1,  /* no specialised kernel: caller uses the generic composition */
+    SG3_BAD_ARG     = -2,
+    SG3_HIP_ERROR   = -3,
+};
+
+/* element types of activation tensors */
+enum {
+    SG3_F32 = 0,
+    SG3_F16 = 1,
+    SG3_F64 = 2,   /* bias_act / upfirdn2d / filtered_lrelu_act only */
+};
+
+int         sg3_abi_version(void);
+const char* sg3_last_error(void);
+/* number of HIP devices visible to the library (0 on a CPU-only host; never fails) */
+int         sg3_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * filtered_lrelu  -- replaces filtered_lrelu_plugin.filtered_lrelu
+ *   (torch_utils/ops/filtered_lrelu.cpp:16-209; parameter block
+ *    torch_utils/ops/filtered_lrelu.h:14-53).
+ *
+ *   y = down_fd( clamp( lrelu( up_fu(x + b) * up^2 * gain ) ) )
+ *
+ * Shapes are NCHW; strides are in ELEMENTS (not bytes), order n,c,h,w.
+ * fu/fd are float32 device arrays.  fuH == 0 (fdH == 0) means a separable
+ * filter of fuW (fdW) taps applied along both axes; otherwise a full
+ * fuH x fuW filter with row stride fuW.
+ * signs: uint8 [N, C, sH, sWbytes], 2 bits per element of the upsampled
+ * buffer (bit0 = negative, value 2 = clamped), 4 elements per byte along x
+ * (torch_utils/ops/filtered_lrelu.cpp:87-94).  NULL when unused.
+ * ---------------------------------------------------------------------- */
+typedef struct sg3_filtered_lrelu_params {
+    const void*    x;          /* [N,C,xH,xW] */
+    void*          y;          /* [N,C,yH,yW] */
+    const void*    b;          /* [C] bias, same dtype as x (never NULL; caller passes zeros) */
+    uint8_t*       s;          /* sign tensor or NULL */
+    const float*   fu;         /* upsampling taps */
+    const float*   fd;         /* downsampling taps */
+    int32_t        dtype;      /* SG3_F32 | SG3_F16 */
+    int32_t        N, C;
+    int32_t        xH, xW;
+    int32_t        yH, yW;
+    int64_t        xStride[4]; /* elements, n,c,h,w */
+    int64_t        yStride[4];
+    int64_t        bStride;
+    int32_t        up, down;
+    int32_t        fuW, fuH;   /* fuH == 0: separable */
+    int32_t        fdW, fdH;
+    int32_t        px0, py0;   /* left / top padding w.r.t. the upsampled image */
+    int32_t        sH;         /* sign tensor height (rows) */
+    int32_t        sWbytes;    /* sign tensor row pitch in bytes */
+    int32_t        sx, sy;     /* offset between upsampled buffer and sign tensor */
+    int32_t        swLimit;    /* active width of the sign tensor in bytes */
+    float          gain;
+    float          slope;
+    float          clamp;      /* +inf = no clamp */
+    int32_t        flip;       /* 1 = correlation (flip_filter=True) */
+    int32_t        writeSigns;
+    int32_t        readSigns;
+} sg3_filtered_lrelu_params;
+
+int sg3_filtered_lrelu(const sg3_filtered_lrelu_params* p, void* stream);
+
+/* 1 when sg3_filtered_lrelu has a fused kernel for this tuple (host-only
+ * query; mirrors the reference's choose_filtered_lrelu_kernel test call,
+ * torch_utils/ops/filtered_lrelu.cpp:46-56). */
+int sg3_filtered_lrelu_has_kernel(int up, int down, int fuW, int fuH, int fdW, int fdH);
+
+/* Output / sign-tensor geometry exactly as the reference host code derives it
+ * (torch_utils/ops/filtered_lrelu.cpp:59-98).  Returns SG3_BAD_ARG when the
+ * reference would raise.  Any out pointer may be NULL. */
+int sg3_filtered_lrelu_shape(int xH, int xW, int up, int down,
+                             int fuW, int fuH, int fdW, int fdH,
+                             int px0, int px1, int py0, int py1,
+                             int* yH, int* yW,
+                             int* sH, int* sWbytes, int* swLimit);
+
+/* ------------------------------------------------------------------------
+ * filtered_lrelu_act  -- replaces filtered_lrelu_plugin.filtered_lrelu_act_
+ *   (torch_utils/ops/filtered_lrelu.cpp:213-290; filtered_lrelu.h:55-68).
+ * In-place gain * lrelu * clamp on x with optional sign write / read.
+ * sW is the sign tensor width in ELEMENTS (multiple of 16).
+ * ---------------------------------------------------------------------- */
+typedef struct sg3_filtered_lrelu_act_params {
+    void*          x;          /* [N,C,H,W], modified in place */
+    uint8_t*       s;          /* [N,C,sH,sW/4] or NULL */
+    int32_t        dtype;      /* SG3_F32 | SG3_F16 | SG3_F64 */
+    int32_t        N, C, H, W;
+    int64_t        xStride[4]; /* elements */
+    int32_t        sH, sW;
+    int32_t        sx, sy;
+    float          gain, slope, clamp;
+    int32_t        writeSigns;
+    int32_t        readSigns;
+} sg3_filtered_lrelu_act_params;
+
+int sg3_filtered_lrelu_act(const sg3_filtered_lrelu_act_params* p, void* stream);
+
+/* ------------------------------------------------------------------------
+ * upfirdn2d  -- replaces upfirdn2d_plugin.upfirdn2d
+ *   (torch_utils/ops/upfirdn2d.cpp:16-98; upfirdn2d.h:14-40).
+ * f is a rank-2 float32 filter [fH, fW] with element strides fStride[2]
+ * (h, w).  Separable filters are two calls, as in the reference Python
+ * (torch_utils/ops/upfirdn2d.py:244-246).
+ * ---------------------------------------------------------------------- */
+typedef struct sg3_upfirdn2d_params {
+    const void*    x;          /* [N,C,xH,xW] */
+    const float*   f;          /* [fH,fW] */
+    void*          y;          /* [N,C,yH,yW] */
+    int32_t        dtype;      /* SG3_F32 | SG3_F16 | SG3_F64 */
+    int32_t        N, C, xH, xW, yH, yW;
+    int64_t        xStride[4];
+    int64_t        yStride[4];
+    int32_t        fH, fW;
+    int64_t        fStride[2];
+    int32_t        upx, upy, downx, downy;
+    int32_t        padx0, pady0;
+    int32_t        flip;
+    float          gain;
+} sg3_upfirdn2d_params;
+
+int sg3_upfirdn2d(const sg3_upfirdn2d_params* p, void* stream);
+
+int sg3_upfirdn2d_shape(int xH, int xW, int fH, int fW,
+                        int upx, int upy, int downx, int downy,
+                        int padx0, int padx1, int pady0, int pady1,
+                        int* yH, int* yW);
+
+/* ------------------------------------------------------------------------
+ * bias_act  -- replaces bias_act_plugin.bias_act
+ *   (torch_utils/ops/bias_act.cpp:32-92; bias_act.h:12-31; kernel semantics
+ *    torch_utils/ops/bias_act.cu:23-147).
+ * x is dense with `sizeX` elements; b (or NULL) has sizeB elements and
+ * element i of x uses b[(i / stepB) % sizeB].  grad = 0 forward, 1 first
+ * derivative, 2 second derivative.  act = 1..9 in the reference's order
+ * (linear, relu, lrelu, tanh, sigmoid, elu, selu, softplus, swish).
+ * clamp < 0 = none.
+ * ---------------------------------------------------------------------- */
+typedef struct sg3_bias_act_params {
+    const void*    x;
+    const void*    b;
+    const void*    xref;
+    const void*    yref;
+    const void*    dy;
+    void*          y;
+    int32_t        dtype;      /* SG3_F32 | SG3_F16 | SG3_F64 */
+    int32_t        grad;
+    int32_t        act;
+    float          alpha, gain, clamp;
+    int64_t        sizeX;
+    int32_t        sizeB;
+    int32_t        stepB;
+} sg3_bias_act_params;
+
+int sg3_bias_act(const sg3_bias_act_params* p, void* stream);
+
+/* ------------------------------------------------------------------------
+ * modulated_conv2d -- replaces the grouped F.conv2d behind
+ *   models/stylegan3/networks_stylegan3.py:24-63 (modulated_conv2d), reached
+ *   through torch_utils/ops/conv2d_gradfix.py:36-39.
+ *
+ *   out[n,o,:,:] = dcoef[n,o] * sum_{i,ky,kx} w[o,i,ky,kx] *
+ *                  (x[n,i,:,:] * sIn[n,i]) (zero padded by `pad`)
+ *
+ * i.e. the per-sample modulation is applied to the INPUT channels and the
+ * demodulation to the OUTPUT channels, so the whole batch shares one weight
+ * matrix and runs as a single implicit GEMM (M = O, N = batch*pixels,
+ * K = I*k*k) on the fp32 matrix cores.  The caller supplies
+ *   w     [O,I,k,k] float32, already pre-normalised when demodulating,
+ *   sIn   [N,I]     float32 = styles (pre-normalised) * input_gain,
+ *   dcoef [N,O]     float32 demodulation coefficients, or NULL (ToRGB).
+ * x / out are NCHW contiguous, dtype f32 or f16; accumulation is fp32.
+ * outH = H + 2*pad - k + 1.
+ * ---------------------------------------------------------------------- */
+typedef struct sg3_modconv_params {
+    const void*    x;          /* [N,I,H,W] */
+    const float*   w;          /* [O,I,k,k] */
+    const float*   sIn;        /* [N,I] */
+    const float*   dcoef;      /* [N,O] or NULL */
+    void*          out;        /* [N,O,outH,outW] */
+    int32_t        dtype;      /* SG3_F32 | SG3_F16 (x and out) */
+    int32_t        N, I, O, H, W;
+    int32_t        k;          /* 1 or 3 */
+    int32_t        pad;
+} sg3_modconv_params;
+
+int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream);
+
+/* Demodulation coefficients and input scales for sg3_modulated_conv2d
+ * (models/stylegan3/networks_stylegan3.py:39-56):
+ *   wn    = w * rsqrt(mean(w^2 over I,k,k))          (per O)    -> wOut [O,I,k,k]
+ *   sn    = s * rsqrt(mean(s^2 over N,I))
+ *   dcoef = rsqrt( sum_{i,k} (wn[o,i,k] * sn[n,i])^2 + 1e-8 )   -> dcoef [N,O]
+ *   sIn   = sn * inputGain                                      -> sIn [N,I]
+ * With demodulate == 0: wOut = w, sIn = s * inputGain, dcoef untouched.
+ * inputGain is a DEVICE pointer (it derives from the magnitude_ema buffer,
+ * :344) read according to inputGainMode: 0 none, 1 one scalar, 2 [I], 3 [N,I].
+ * `wsq` is scratch [O,I] float32.
+ * ---------------------------------------------------------------------- */
+typedef struct sg3_modconv_prep_params {
+    const float*   w;          /* [O,I,k,k] */
+    const float*   s;          /* [N,I] */
+    float*         wOut;       /* [O,I,k,k] */
+    float*         wsq;        /* [O,I] scratch */
+    float*         sIn;        /* [N,I] */
+    float*         dcoef;      /* [N,O] (NULL allowed when demodulate == 0) */
+    const float*   inputGain;  /* device pointer or NULL */
+    int32_t        inputGainMode;
+    int32_t        N, I, O, k;
+    int32_t        demodulate;
+} sg3_modconv_prep_params;
+
+int sg3_modulated_conv2d_prep(const sg3_modconv_prep_params* p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SG3_OPS_H */

@@ -1,0 +1,424 @@
+"""StyleGAN3 alias-free generator graph for the MI355X build.
+
+Public surface, constructor arguments and parameter / buffer names are those of the reference graph
+(reference models/stylegan3/networks_stylegan3.py: modulated_conv2d :24, FullyConnectedLayer :68, MappingNetwork
+:108, SynthesisInput :168, SynthesisLayer :259, SynthesisNetwork :406 with the fork's StyleSpace `all_s` path and
+`W2S` :503, Generator :531), so `.pt` state_dicts load unchanged and callers (pSp/e4e wrappers, PTI, FOV expansion,
+StyleCLIP sweeps) keep working.  The implementation is organised differently:
+
+  * the per-layer geometry (cutoffs, sampling rates, sizes, channels, up/down factors, taps, padding) is computed
+    once by `synthesis_schedule()` as a table of `LayerGeometry` records that SynthesisNetwork hands to its layers
+    (and that bench.py uses for byte / FLOP accounting);
+  * the modulated convolution runs as one batch-wide MFMA implicit GEMM (torch_utils/ops/modulated_conv.py)
+    instead of a grouped convolution over N-fold expanded weights;
+  * bias + up-FIR + lrelu + clamp + down-FIR is the fused streaming HIP kernel behind
+    torch_utils.ops.filtered_lrelu.
+
+Small dense algebra that the reference also leaves to the BLAS library (the 512-wide affine / mapping layers and
+the 36x36 Fourier-feature GEMM) stays on torch ops.
+"""
+import collections
+
+import numpy as np
+import scipy.signal
+import scipy.special
+import torch
+
+from torch_utils import misc, persistence
+from torch_utils.ops import bias_act, filtered_lrelu
+from torch_utils.ops import modulated_conv as _modconv
+
+# ----------------------------------------------------------------------------
+
+
+@misc.profiled_function
+def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None):
+    """x [N,I,H,W], w [O,I,kh,kw], s [N,I], input_gain [] | [I] | [N,I]  ->  [N,O,H',W'].
+
+    Equals a per-sample convolution with weights  w * s[n] (unit-normalised and demodulated when `demodulate`) times
+    `input_gain` (reference :24-63)."""
+    return _modconv.modulated_conv2d(x, w, s, demodulate=demodulate, padding=padding, input_gain=input_gain)
+
+# ----------------------------------------------------------------------------
+
+
+@persistence.persistent_class
+class FullyConnectedLayer(torch.nn.Module):
+    """y = act(x @ (W * lr_mul / sqrt(in)).T + b * lr_mul)   (equalised learning rate)."""
+
+    def __init__(self, in_features, out_features, activation='linear', bias=True, lr_multiplier=1, weight_init=1, bias_init=0):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.activation = activation
+        self.weight = torch.nn.Parameter(torch.randn([out_features, in_features]) * (weight_init / lr_multiplier))
+        b0 = np.broadcast_to(np.asarray(bias_init, dtype=np.float32), [out_features])
+        self.bias = torch.nn.Parameter(torch.from_numpy(b0 / lr_multiplier)) if bias else None
+        self.weight_gain = lr_multiplier / np.sqrt(in_features)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):
+        w = self.weight.to(x.dtype) * self.weight_gain
+        b = self.bias
+        if b is not None:
+            b = b.to(x.dtype)
+            if self.bias_gain != 1:
+                b = b * self.bias_gain
+        if self.activation == 'linear' and b is not None:
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+
+    def extra_repr(self):
+        return f'in_features={self.in_features:d}, out_features={self.out_features:d}, activation={self.activation:s}'
+
+# ----------------------------------------------------------------------------
+
+
+@persistence.persistent_class
+class MappingNetwork(torch.nn.Module):
+    """z (and optional label c) -> num_ws copies of the intermediate latent w, with truncation towards w_avg."""
+
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=2, lr_multiplier=0.01, w_avg_beta=0.998):
+        super().__init__()
+        self.z_dim = z_dim
+        self.c_dim = c_dim
+        self.w_dim = w_dim
+        self.num_ws = num_ws
+        self.num_layers = num_layers
+        self.w_avg_beta = w_avg_beta
+        self.embed = FullyConnectedLayer(c_dim, w_dim) if c_dim > 0 else None
+        widths = [z_dim + (w_dim if c_dim > 0 else 0)] + [w_dim] * num_layers
+        for i in range(num_layers):
+            setattr(self, f'fc{i}', FullyConnectedLayer(widths[i], widths[i + 1], activation='lrelu', lr_multiplier=lr_multiplier))
+        self.register_buffer('w_avg', torch.zeros([w_dim]))
+
+    @staticmethod
+    def _unit_rms(v):
+        return v * (v.square().mean(1, keepdim=True) + 1e-8).rsqrt()
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False):
+        misc.assert_shape(z, [None, self.z_dim])
+        x = self._unit_rms(z.to(torch.float32))
+        if self.c_dim > 0:
+            misc.assert_shape(c, [None, self.c_dim])
+            x = torch.cat([x, self._unit_rms(self.embed(c.to(torch.float32)))], dim=1)
+        for i in range(self.num_layers):
+            x = getattr(self, f'fc{i}')(x)
+        if update_emas:
+            self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        ws = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            cut = self.num_ws if truncation_cutoff is None else truncation_cutoff
+            ws[:, :cut] = self.w_avg.lerp(ws[:, :cut], truncation_psi)
+        return ws
+
+    def extra_repr(self):
+        return f'z_dim={self.z_dim:d}, c_dim={self.c_dim:d}, w_dim={self.w_dim:d}, num_ws={self.num_ws:d}'
+
+# ----------------------------------------------------------------------------
+
+
+@persistence.persistent_class
+class SynthesisInput(torch.nn.Module):
+    """Fourier-feature input: `channels` sinusoids with frequencies inside a disc of radius `bandwidth`, transformed by
+    a learned rotation+translation (from w) and by the user-assignable `transform` buffer ([3,3] or [B,3,3])."""
+
+    def __init__(self, w_dim, channels, size, sampling_rate, bandwidth):
+        super().__init__()
+        self.w_dim = w_dim
+        self.channels = channels
+        self.size = np.broadcast_to(np.asarray(size), [2])
+        self.sampling_rate = sampling_rate
+        self.bandwidth = bandwidth
+
+        freqs = torch.randn([channels, 2])
+        radii = freqs.square().sum(dim=1, keepdim=True).sqrt()
+        freqs = freqs / (radii * radii.square().exp().pow(0.25)) * bandwidth
+        phases = torch.rand([channels]) - 0.5
+
+        self.weight = torch.nn.Parameter(torch.randn([channels, channels]))
+        self.affine = FullyConnectedLayer(w_dim, 4, weight_init=0, bias_init=[1, 0, 0, 0])
+        self.register_buffer('transform', torch.eye(3, 3))
+        self.register_buffer('freqs', freqs)
+        self.register_buffer('phases', phases)
+
+    def transform_params(self, w):
+        """(r_c, r_s, t_x, t_y) predicted from w, rotation part normalised to unit length."""
+        t = self.affine(w)
+        return t / t[:, :2].norm(dim=1, keepdim=True)
+
+    def forward(self, w, t=None):
+        if t is None:
+            t = self.transform_params(w)
+        device, n = t.device, t.shape[0]
+        # inverse rotation, then inverse translation, then the user transform (all w.r.t. the output image)
+        rot = torch.eye(3, device=device).repeat(n, 1, 1)
+        rot[:, 0, 0], rot[:, 0, 1], rot[:, 1, 0], rot[:, 1, 1] = t[:, 0], -t[:, 1], t[:, 1], t[:, 0]
+        trans = torch.eye(3, device=device).repeat(n, 1, 1)
+        trans[:, 0, 2], trans[:, 1, 2] = -t[:, 2], -t[:, 3]
+        m = rot @ trans @ self.transform
+
+        freqs = self.freqs.unsqueeze(0)
+        phases = self.phases.unsqueeze(0) + (freqs @ m[:, :2, 2:]).squeeze(2)
+        freqs = freqs @ m[:, :2, :2]
+        # fade out frequencies that the transform pushed beyond the band limit
+        amps = (1 - (freqs.norm(dim=2) - self.bandwidth) / (self.sampling_rate / 2 - self.bandwidth)).clamp(0, 1)
+
+        theta = torch.eye(2, 3, device=device)
+        theta[0, 0] = 0.5 * self.size[0] / self.sampling_rate
+        theta[1, 1] = 0.5 * self.size[1] / self.sampling_rate
+        grid = torch.nn.functional.affine_grid(theta.unsqueeze(0), [1, 1, self.size[1], self.size[0]], align_corners=False)
+
+        x = (grid.unsqueeze(3) @ freqs.permute(0, 2, 1).unsqueeze(1).unsqueeze(2)).squeeze(3)   # [N,H,W,C]
+        x = torch.sin((x + phases.unsqueeze(1).unsqueeze(2)) * (np.pi * 2)) * amps.unsqueeze(1).unsqueeze(2)
+        x = x @ (self.weight / np.sqrt(self.channels)).t()
+        x = x.permute(0, 3, 1, 2)
+        misc.assert_shape(x, [n, self.channels, int(self.size[1]), int(self.size[0])])
+        return x
+
+    def extra_repr(self):
+        return '\n'.join([
+            f'w_dim={self.w_dim:d}, channels={self.channels:d}, size={list(self.size)},',
+            f'sampling_rate={self.sampling_rate:g}, bandwidth={self.bandwidth:g}'])
+
+# ----------------------------------------------------------------------------
+
+
+def design_lowpass_filter(numtaps, cutoff, width, fs, radial=False):
+    """Kaiser-window low-pass taps (float32 tensor), or None for the identity (numtaps == 1).
+
+    Separable: scipy.signal.firwin(numtaps, cutoff, width, fs).  Radial: jinc(2*cutoff*r) sampled on the tap grid,
+    windowed by the outer product of the same Kaiser window, normalised to unit DC gain (reference :370-391)."""
+    assert numtaps >= 1
+    if numtaps == 1:
+        return None
+    if not radial:
+        return torch.as_tensor(scipy.signal.firwin(numtaps=numtaps, cutoff=cutoff, width=width, fs=fs), dtype=torch.float32)
+    pos = (np.arange(numtaps) - (numtaps - 1) / 2) / fs
+    r = np.hypot(*np.meshgrid(pos, pos))
+    taps = scipy.special.j1(2 * cutoff * (np.pi * r)) / (np.pi * r)
+    window = np.kaiser(numtaps, scipy.signal.kaiser_beta(scipy.signal.kaiser_atten(numtaps, width / (fs / 2))))
+    taps = taps * np.outer(window, window)
+    return torch.as_tensor(taps / np.sum(taps), dtype=torch.float32)
+
+
+@persistence.persistent_class
+class SynthesisLayer(torch.nn.Module):
+    """affine(w) -> modulated conv -> fused {bias, upsample FIR, leaky ReLU, clamp, downsample FIR}."""
+
+    def __init__(self, w_dim, is_torgb, is_critically_sampled, use_fp16,
+                 in_channels, out_channels, in_size, out_size, in_sampling_rate, out_sampling_rate,
+                 in_cutoff, out_cutoff, in_half_width, out_half_width,
+                 conv_kernel=3, filter_size=6, lrelu_upsampling=2, use_radial_filters=False, conv_clamp=256,
+                 magnitude_ema_beta=0.999):
+        super().__init__()
+        self.w_dim = w_dim
+        self.is_torgb = is_torgb
+        self.is_critically_sampled = is_critically_sampled
+        self.use_fp16 = use_fp16
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.in_size = np.broadcast_to(np.asarray(in_size), [2])
+        self.out_size = np.broadcast_to(np.asarray(out_size), [2])
+        self.in_sampling_rate = in_sampling_rate
+        self.out_sampling_rate = out_sampling_rate
+        self.tmp_sampling_rate = max(in_sampling_rate, out_sampling_rate) * (1 if is_torgb else lrelu_upsampling)
+        self.in_cutoff = in_cutoff
+        self.out_cutoff = out_cutoff
+        self.in_half_width = in_half_width
+        self.out_half_width = out_half_width
+        self.conv_kernel = 1 if is_torgb else conv_kernel
+        self.conv_clamp = conv_clamp
+        self.magnitude_ema_beta = magnitude_ema_beta
+
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, self.conv_kernel, self.conv_kernel]))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+        self.register_buffer('magnitude_ema', torch.ones([]))
+
+        # resampling factors and FIR filters around the non-linearity
+        self.up_factor = int(np.rint(self.tmp_sampling_rate / in_sampling_rate))
+        assert in_sampling_rate * self.up_factor == self.tmp_sampling_rate
+        self.up_taps = filter_size * self.up_factor if self.up_factor > 1 and not is_torgb else 1
+        self.register_buffer('up_filter', self.design_lowpass_filter(
+            numtaps=self.up_taps, cutoff=in_cutoff, width=in_half_width * 2, fs=self.tmp_sampling_rate))
+        self.down_factor = int(np.rint(self.tmp_sampling_rate / out_sampling_rate))
+        assert out_sampling_rate * self.down_factor == self.tmp_sampling_rate
+        self.down_taps = filter_size * self.down_factor if self.down_factor > 1 and not is_torgb else 1
+        self.down_radial = use_radial_filters and not is_critically_sampled
+        self.register_buffer('down_filter', self.design_lowpass_filter(
+            numtaps=self.down_taps, cutoff=out_cutoff, width=out_half_width * 2, fs=self.tmp_sampling_rate, radial=self.down_radial))
+
+        # padding so that the decimated output has exactly out_size samples, centred per Appendix C.3 of the paper
+        total = (self.out_size - 1) * self.down_factor + 1
+        total = total - (self.in_size + self.conv_kernel - 1) * self.up_factor
+        total = total + self.up_taps + self.down_taps - 2
+        lo = (total + self.up_factor) // 2
+        hi = total - lo
+        self.padding = [int(lo[0]), int(hi[0]), int(lo[1]), int(hi[1])]
+
+    design_lowpass_filter = staticmethod(design_lowpass_filter)
+
+    def styles_from_w(self, w):
+        """Per-input-channel modulation for latent w (ToRGB styles carry the 1/sqrt(fan_in) weight gain)."""
+        styles = self.affine(w)
+        if self.is_torgb:
+            styles = styles * (1 / np.sqrt(self.in_channels * (self.conv_kernel ** 2)))
+        return styles
+
+    def forward(self, x, w, styles=None, noise_mode='random', force_fp32=False, update_emas=False):
+        assert noise_mode in ['random', 'const', 'none']  # kept for API compatibility; SG3 has no noise inputs
+        misc.assert_shape(x, [None, self.in_channels, int(self.in_size[1]), int(self.in_size[0])])
+        if update_emas:
+            with torch.autograd.profiler.record_function('update_magnitude_ema'):
+                cur = x.detach().to(torch.float32).square().mean()
+                self.magnitude_ema.copy_(cur.lerp(self.magnitude_ema, self.magnitude_ema_beta))
+        input_gain = self.magnitude_ema.rsqrt()
+
+        if styles is None:
+            misc.assert_shape(w, [x.shape[0], self.w_dim])
+            styles = self.styles_from_w(w)
+
+        dtype = torch.float16 if (self.use_fp16 and not force_fp32 and x.device.type == 'cuda') else torch.float32
+        x = modulated_conv2d(x=x.to(dtype), w=self.weight, s=styles, padding=self.conv_kernel - 1,
+                             demodulate=(not self.is_torgb), input_gain=input_gain)
+        x = filtered_lrelu.filtered_lrelu(
+            x=x, fu=self.up_filter, fd=self.down_filter, b=self.bias.to(x.dtype), up=self.up_factor, down=self.down_factor,
+            padding=self.padding, gain=(1 if self.is_torgb else np.sqrt(2)), slope=(1 if self.is_torgb else 0.2), clamp=self.conv_clamp)
+        misc.assert_shape(x, [None, self.out_channels, int(self.out_size[1]), int(self.out_size[0])])
+        assert x.dtype == dtype
+        return x
+
+    def extra_repr(self):
+        return '\n'.join([
+            f'w_dim={self.w_dim:d}, is_torgb={self.is_torgb},',
+            f'is_critically_sampled={self.is_critically_sampled}, use_fp16={self.use_fp16},',
+            f'in_sampling_rate={self.in_sampling_rate:g}, out_sampling_rate={self.out_sampling_rate:g},',
+            f'in_cutoff={self.in_cutoff:g}, out_cutoff={self.out_cutoff:g},',
+            f'in_half_width={self.in_half_width:g}, out_half_width={self.out_half_width:g},',
+            f'in_size={list(self.in_size)}, out_size={list(self.out_size)},',
+            f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}'])
+
+# ----------------------------------------------------------------------------
+
+LayerGeometry = collections.namedtuple('LayerGeometry', [
+    'index', 'is_torgb', 'is_critically_sampled', 'use_fp16', 'in_channels', 'out_channels', 'in_size', 'out_size',
+    'in_sampling_rate', 'out_sampling_rate', 'in_cutoff', 'out_cutoff', 'in_half_width', 'out_half_width'])
+
+
+def synthesis_schedule(img_resolution, img_channels, channel_base=32768, channel_max=512, num_layers=14, num_critical=2,
+                       first_cutoff=2, first_stopband=2 ** 2.1, last_stopband_rel=2 ** 0.3, margin_size=10, num_fp16_res=4):
+    """Geometric progression of cutoffs / stopbands and everything derived from it (reference :430-447, :458).
+
+    Returns (input_spec, [LayerGeometry x (num_layers + 1)]): layer i reads the signal described by entry max(i-1, 0)
+    of the progression and writes entry i; the last entry is the ToRGB layer."""
+    last_cutoff = img_resolution / 2
+    last_stopband = last_cutoff * last_stopband_rel
+    expo = np.minimum(np.arange(num_layers + 1) / (num_layers - num_critical), 1)
+    cutoffs = first_cutoff * (last_cutoff / first_cutoff) ** expo
+    stopbands = first_stopband * (last_stopband / first_stopband) ** expo
+    rates = np.exp2(np.ceil(np.log2(np.minimum(stopbands * 2, img_resolution))))
+    half_widths = np.maximum(stopbands, rates / 2) - cutoffs
+    sizes = rates + margin_size * 2
+    sizes[-2:] = img_resolution
+    channels = np.rint(np.minimum((channel_base / 2) / cutoffs, channel_max))
+    channels[-1] = img_channels
+    input_spec = dict(channels=int(channels[0]), size=int(sizes[0]), sampling_rate=rates[0], bandwidth=cutoffs[0])
+    table = []
+    for i in range(num_layers + 1):
+        p = max(i - 1, 0)
+        table.append(LayerGeometry(
+            index=i, is_torgb=(i == num_layers), is_critically_sampled=(i >= num_layers - num_critical),
+            use_fp16=bool(rates[i] * (2 ** num_fp16_res) > img_resolution),
+            in_channels=int(channels[p]), out_channels=int(channels[i]), in_size=int(sizes[p]), out_size=int(sizes[i]),
+            in_sampling_rate=int(rates[p]), out_sampling_rate=int(rates[i]), in_cutoff=cutoffs[p], out_cutoff=cutoffs[i],
+            in_half_width=half_widths[p], out_half_width=half_widths[i]))
+    return input_spec, table
+
+
+@persistence.persistent_class
+class SynthesisNetwork(torch.nn.Module):
+    def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_layers=14,
+                 num_critical=2, first_cutoff=2, first_stopband=2 ** 2.1, last_stopband_rel=2 ** 0.3, margin_size=10,
+                 output_scale=0.25, num_fp16_res=4, **layer_kwargs):
+        super().__init__()
+        self.w_dim = w_dim
+        self.num_ws = num_layers + 2
+        self.img_resolution = img_resolution
+        self.img_channels = img_channels
+        self.num_layers = num_layers
+        self.num_critical = num_critical
+        self.margin_size = margin_size
+        self.output_scale = output_scale
+        self.num_fp16_res = num_fp16_res
+
+        input_spec, table = synthesis_schedule(
+            img_resolution, img_channels, channel_base=channel_base, channel_max=channel_max, num_layers=num_layers,
+            num_critical=num_critical, first_cutoff=first_cutoff, first_stopband=first_stopband,
+            last_stopband_rel=last_stopband_rel, margin_size=margin_size, num_fp16_res=num_fp16_res)
+        self.input = SynthesisInput(w_dim=w_dim, **input_spec)
+        self.layer_names = []
+        for g in table:
+            kw = g._asdict()
+            kw.pop('index')
+            layer = SynthesisLayer(w_dim=w_dim, **kw, **layer_kwargs)
+            name = f'L{g.index}_{layer.out_size[0]}_{layer.out_channels}'
+            setattr(self, name, layer)
+            self.layer_names.append(name)
+
+    def layers(self):
+        return [getattr(self, n) for n in self.layer_names]
+
+    def forward(self, ws, all_s=None, **layer_kwargs):
+        """ws [N, num_ws, w_dim]  ->  image [N, img_channels, R, R] (fp32).
+        With `all_s` (dict from W2S, possibly edited) the affine layers are bypassed: StyleSpace path."""
+        if all_s is None:
+            misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
+            per_layer = ws.to(torch.float32).unbind(dim=1)
+            x = self.input(per_layer[0])
+            for layer, w in zip(self.layers(), per_layer[1:]):
+                x = layer(x, w, **layer_kwargs)
+        else:
+            x = self.input(None, t=all_s['input'])
+            for name, layer in zip(self.layer_names, self.layers()):
+                x = layer(x, None, styles=all_s[name], **layer_kwargs)
+        if self.output_scale != 1:
+            x = x * self.output_scale
+        misc.assert_shape(x, [None, self.img_channels, self.img_resolution, self.img_resolution])
+        return x.to(torch.float32)
+
+    def W2S(self, ws):
+        """Latents -> StyleSpace: {'input': t [N,4], layer_name: styles [N, in_channels]} (reference :503-525)."""
+        misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
+        per_layer = ws.to(torch.float32).unbind(dim=1)
+        all_s = {'input': self.input.transform_params(per_layer[0])}
+        for name, layer, w in zip(self.layer_names, self.layers(), per_layer[1:]):
+            all_s[name] = layer.styles_from_w(w)
+        return all_s
+
+    def extra_repr(self):
+        return '\n'.join([
+            f'w_dim={self.w_dim:d}, num_ws={self.num_ws:d},',
+            f'img_resolution={self.img_resolution:d}, img_channels={self.img_channels:d},',
+            f'num_layers={self.num_layers:d}, num_critical={self.num_critical:d},',
+            f'margin_size={self.margin_size:d}, num_fp16_res={self.num_fp16_res:d}'])
+
+# ----------------------------------------------------------------------------
+
+
+@persistence.persistent_class
+class Generator(torch.nn.Module):
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, **synthesis_kwargs):
+        super().__init__()
+        self.z_dim = z_dim
+        self.c_dim = c_dim
+        self.w_dim = w_dim
+        self.img_resolution = img_resolution
+        self.img_channels = img_channels
+        self.synthesis = SynthesisNetwork(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, **mapping_kwargs)
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)

@@ -1,0 +1,126 @@
+"""Modulated convolution on the MI355X matrix cores.
+
+This is the op behind `modulated_conv2d()` of the generator graph (reference
+models/stylegan3/networks_stylegan3.py:24-63).  The reference folds style, demodulation and input gain into
+per-sample WEIGHTS [N*O, I, k, k] and calls one grouped cuDNN convolution (:59-62, via
+torch_utils/ops/conv2d_gradfix.py:36-39).  Here the same result is produced by two launches of libsg3hip.so:
+
+  1. sg3_modulated_conv2d_prep: normalised weights wn (once per call), per-sample input scales
+     sIn[n,i] = s'[n,i] * input_gain and demodulation coefficients dcoef[n,o];
+  2. sg3_modulated_conv2d: out[n,o] = dcoef[n,o] * conv(x[n] * sIn[n], wn) as ONE implicit GEMM for the whole
+     batch (M = O, N = pixels, K = I*k*k) on fp32-exact MFMA -- the weights are shared by every sample instead
+     of being expanded N-fold.
+
+Moving the modulation from the weights to the activations is algebraically identical (the products are
+re-associated; differences are fp32 rounding, ~1e-7 relative).  Backward (needed by PTI) re-expresses the op with
+differentiable torch ops and lets autograd differentiate that composite, so first and higher order gradients
+w.r.t. x, w and s are available.
+"""
+import ctypes
+
+import torch
+
+from .. import _sg3abi as abi
+from .. import misc
+
+
+def _composite(x, w, s, demodulate, padding, input_gain):
+    """The reference formulation with plain torch ops (differentiable; also the CPU / impl='ref' path)."""
+    n = int(x.shape[0])
+    o, i, kh, kw = w.shape
+    if demodulate:
+        w = w * w.square().mean([1, 2, 3], keepdim=True).rsqrt()
+        s = s * s.square().mean().rsqrt()
+    w = w.unsqueeze(0) * s.unsqueeze(1).unsqueeze(3).unsqueeze(4)           # [N,O,I,k,k]
+    if demodulate:
+        w = w * (w.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt().unsqueeze(2).unsqueeze(3).unsqueeze(4)
+    if input_gain is not None:
+        w = w * input_gain.expand(n, i).unsqueeze(1).unsqueeze(3).unsqueeze(4)
+    y = torch.nn.functional.conv2d(x.reshape(1, -1, *x.shape[2:]), w.reshape(-1, i, kh, kw).to(x.dtype), padding=padding, groups=n)
+    return y.reshape(n, -1, *y.shape[2:])
+
+
+def _launch(x, w, s, demodulate, padding, input_gain):
+    n, ci, h, wd = (int(v) for v in x.shape)
+    co, ci2, k, k2 = (int(v) for v in w.shape)
+    if k != k2 or ci != ci2 or k not in (1, 3):
+        raise RuntimeError(f'modulated_conv2d: unsupported weight shape {tuple(w.shape)}')
+    if x.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError(f'modulated_conv2d: unsupported dtype {x.dtype}')
+    lib = abi.load()
+    dev = x.device
+    x = x.contiguous()
+    w32 = w.detach().to(torch.float32).contiguous()
+    s32 = s.detach().to(torch.float32).contiguous()
+    gmode, gptr = 0, None
+    if input_gain is not None:
+        g = input_gain.detach().to(device=dev, dtype=torch.float32)
+        if g.numel() == 1:
+            gmode, g = 1, g.reshape(1)
+        elif g.ndim <= 1 or (g.ndim == 2 and g.shape[0] == 1):
+            gmode, g = 2, g.reshape(-1).contiguous()
+            assert g.numel() == ci
+        else:
+            gmode, g = 3, g.expand(n, ci).contiguous()
+        gptr = g
+    wn = torch.empty_like(w32)
+    wsq = torch.empty([co, ci], dtype=torch.float32, device=dev)
+    s_in = torch.empty([n, ci], dtype=torch.float32, device=dev)
+    dcoef = torch.empty([n, co], dtype=torch.float32, device=dev) if demodulate else None
+    oh, ow = h + 2 * padding - k + 1, wd + 2 * padding - k + 1
+    out = torch.empty([n, co, oh, ow], dtype=x.dtype, device=dev)
+    stream = abi.stream_ptr(dev)
+    with torch.cuda.device(dev):
+        pp = abi.ModconvPrepParams()
+        pp.w, pp.s, pp.wOut, pp.wsq, pp.sIn, pp.dcoef = abi.ptr(w32), abi.ptr(s32), abi.ptr(wn), abi.ptr(wsq), abi.ptr(s_in), abi.ptr(dcoef)
+        pp.inputGain, pp.inputGainMode = abi.ptr(gptr), gmode
+        pp.N, pp.I, pp.O, pp.k, pp.demodulate = n, ci, co, k, int(bool(demodulate))
+        abi.check(lib.sg3_modulated_conv2d_prep(ctypes.byref(pp), stream), 'sg3_modulated_conv2d_prep')
+        cp = abi.ModconvParams()
+        cp.x, cp.w, cp.sIn, cp.dcoef, cp.out = abi.ptr(x), abi.ptr(wn), abi.ptr(s_in), abi.ptr(dcoef), abi.ptr(out)
+        cp.dtype = abi.dtype_code(x.dtype)
+        cp.N, cp.I, cp.O, cp.H, cp.W, cp.k, cp.pad = n, ci, co, h, wd, k, int(padding)
+        abi.check(lib.sg3_modulated_conv2d(ctypes.byref(cp), stream), 'sg3_modulated_conv2d')
+    return out
+
+
+class _ModulatedConv2dHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, s, input_gain, demodulate, padding):  # pylint: disable=arguments-differ
+        ctx.save_for_backward(x, w, s, input_gain if input_gain is not None else torch.empty(0))
+        ctx.cfg = (demodulate, padding, input_gain is not None)
+        return _launch(x, w, s, demodulate, padding, input_gain)
+
+    @staticmethod
+    def backward(ctx, dy):  # pylint: disable=arguments-differ
+        x, w, s, g = ctx.saved_tensors
+        demodulate, padding, has_gain = ctx.cfg
+        need = ctx.needs_input_grad
+        ins, idx = [], []
+        with torch.enable_grad():
+            xd = x.detach().requires_grad_(need[0]); wd = w.detach().requires_grad_(need[1]); sd = s.detach().requires_grad_(need[2])
+            gd = g.detach().requires_grad_(need[3]) if has_gain else None
+            for j, t in enumerate((xd, wd, sd, gd)):
+                if t is not None and need[j]:
+                    ins.append(t); idx.append(j)
+            y = _composite(xd, wd, sd, demodulate, padding, gd)
+            grads = torch.autograd.grad(y, ins, dy, create_graph=torch.is_grad_enabled(), allow_unused=True) if ins else []
+        out = [None] * 6
+        for j, gr in zip(idx, grads):
+            out[j] = gr
+        return tuple(out)
+
+
+@misc.profiled_function
+def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, impl='cuda'):
+    """x [N,I,H,W], w [O,I,k,k], s [N,I]; input_gain [], [I] or [N,I].  Returns [N,O,H+2p-k+1,W+2p-k+1] in x.dtype."""
+    assert impl in ['ref', 'cuda']
+    with misc.suppress_tracer_warnings():
+        n = int(x.shape[0])
+    o, i, kh, kw = w.shape
+    misc.assert_shape(w, [o, i, kh, kw])
+    misc.assert_shape(x, [n, i, None, None])
+    misc.assert_shape(s, [n, i])
+    if impl == 'cuda' and x.device.type == 'cuda':
+        return _ModulatedConv2dHip.apply(x, w, s, input_gain, bool(demodulate), int(padding))
+    return _composite(x, w, s, demodulate, padding, input_gain)
