@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- FFHQ-1024 StyleGAN3-T synthesis throughput on MI355X (BASELINE.json configs[1]).
+
+A "step" is one `Generator.synthesis(ws)` forward over a batch of 8 synthetic latents per GPU (seeded random
+weights of the config-T 1024 architecture: there are no pretrained weights offline), fp32 execution
+(`force_fp32=True`, the mode the 1e-4 parity target is stated for).  Inputs and weights are resident in HBM before the
+timed region.  With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank runs the same
+per-GPU batch on its own images (weak scaling, no data-path collective: images are independent units); the timed
+region is bracketed by barrier + synchronize and the MAX over ranks is reported.
+
+One JSON line is printed by rank 0:
+  metric/value : whole-job images per second
+  roofline     : filtered_lrelu streaming kernel -- algorithmic bytes (C*(in^2+out^2)*4 per image and layer,
+                 SURVEY 8d) / its summed launch time measured with HIP events on the launch stream, vs 8 TB/s
+  cpu_baseline : the CPU oracle (C/OpenMP port of the reference ref path) timed on this host for ONE image
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, 'stylegan3-editing_amd'), os.path.join(ROOT, 'tests'), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def build_generator(cfg, device):
+    from models.stylegan3.networks_stylegan3 import Generator
+    from synth_weights import CONFIGS, synth_state_dict
+    G = Generator(**CONFIGS[cfg]).eval().requires_grad_(False)
+    man = {k: list(v.shape) for k, v in G.state_dict().items()}
+    sd = synth_state_dict(man, seed=0, input_bandwidth=float(G.synthesis.input.bandwidth))
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    return G.to(device)
+
+
+def flrelu_algorithmic_bytes(G, batch, elem_size=4):
+    """Sum over synthesis layers of C_out * (in^2 + out^2) * sizeof (read conv output once, write activation once)."""
+    total = 0
+    per_layer = {}
+    for name in G.synthesis.layer_names:
+        layer = getattr(G.synthesis, name)
+        k = layer.conv_kernel
+        ins = int(layer.in_size[0]) + k - 1
+        outs = int(layer.out_size[0])
+        nbytes = batch * layer.out_channels * (ins * ins + outs * outs) * elem_size
+        per_layer[name] = nbytes
+        total += nbytes
+    return total, per_layer
+
+
+class KernelTimer:
+    """Brackets every filtered_lrelu / modulated_conv2d ABI launch with HIP events on the launch stream."""
+
+    def __init__(self):
+        self.records = {'filtered_lrelu': [], 'modulated_conv2d': []}
+        self.enabled = False
+
+    def install(self):
+        from torch_utils import _hip_plugins
+        from torch_utils.ops import modulated_conv
+        timer = self
+        orig_f = _hip_plugins.FilteredLreluPlugin.filtered_lrelu
+        orig_c = modulated_conv._launch
+
+        def timed_flrelu(x, *a, **k):
+            if not timer.enabled:
+                return orig_f(x, *a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_f(x, *a, **k)
+            e1.record()
+            timer.records['filtered_lrelu'].append((e0, e1))
+            return out
+
+        def timed_conv(x, *a, **k):
+            if not timer.enabled:
+                return orig_c(x, *a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_c(x, *a, **k)
+            e1.record()
+            timer.records['modulated_conv2d'].append((e0, e1))
+            return out
+
+        _hip_plugins.FilteredLreluPlugin.filtered_lrelu = staticmethod(timed_flrelu)
+        modulated_conv._launch = timed_conv
+
+    def total_ms(self, key):
+        return sum(e0.elapsed_time(e1) for e0, e1 in self.records[key])
+
+
+def cpu_baseline(cfg):
+    """CPU oracle (oracle/: C + OpenMP restatement of the reference's ref path) on ONE image of the same workload."""
+    from helpers import build_oracle_generator
+    from oracle import oracle as O
+    from synth_weights import synth_ws
+    sd, sched = build_oracle_generator(cfg)
+    ws = synth_ws(1, sched['num_ws'], sched['w_dim'], seed=1)
+    t0 = time.time()
+    O.synthesis(sd, sched, ws=ws)
+    dt = time.time() - t0
+    return dict(value=1.0 / dt, unit='imgs/s', cores=O.num_threads(), kind='port',
+                sample=f'1 image, {cfg} synthesis forward fp32, {dt:.1f} s on {O.num_threads()} OpenMP threads')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    ap.add_argument('--config', default='T1024')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the product has no CPU fallback for the timed path)'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    from torch_utils import _sg3abi
+    _sg3abi.load()
+    from synth_weights import synth_ws
+    G = build_generator(args.config, device)
+    # each rank owns its own shard of images (independent units; seeds differ per rank)
+    ws = torch.from_numpy(synth_ws(args.batch, G.num_ws, G.w_dim, seed=1 + rank)).to(device)
+
+    timer = KernelTimer()
+    timer.install()
+
+    def step():
+        with torch.no_grad():
+            return G.synthesis(ws, noise_mode='const', force_fp32=True)
+
+    launches0 = _sg3abi.launch_count
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    assert _sg3abi.launch_count - launches0 >= args.warmup * 30 or args.warmup == 0, 'HIP kernels did not run'
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    assert tuple(img.shape) == (args.batch, 3, G.img_resolution, G.img_resolution) and bool(torch.isfinite(img).all())
+
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        total_bytes, _ = flrelu_algorithmic_bytes(G, args.batch)
+        fl_ms = timer.total_ms('filtered_lrelu') / max(args.steps, 1)        # per step, all 15 launches
+        conv_ms = timer.total_ms('modulated_conv2d') / max(args.steps, 1)
+        achieved = total_bytes / (fl_ms * 1e-3) / 1e9 if fl_ms > 0 else 0.0
+        conv_flop = 0
+        for name in G.synthesis.layer_names:
+            layer = getattr(G.synthesis, name)
+            s = int(layer.in_size[0]) + layer.conv_kernel - 1
+            conv_flop += 2 * layer.in_channels * layer.out_channels * layer.conv_kernel ** 2 * s * s * args.batch
+        out = {
+            'metric': 'FFHQ-1024 StyleGAN3-T synthesis imgs/sec', 'value': args.batch * world * args.steps / dt, 'unit': 'imgs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'StyleGAN3-T FFHQ-1024 Generator.synthesis forward, batch {args.batch} per GPU, force_fp32 '
+                                   f'(BASELINE configs[1]); seeded random weights', 'per_gpu_batch': args.batch, 'sharding': 'images'},
+            'roofline': {'bound': 'hbm', 'kernel': 'flrelu_stream_kernel (+pointwise ToRGB)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'algorithmic_bytes_per_step': total_bytes, 'kernel_ms_per_step': fl_ms},
+            'modconv': {'bound': 'mfma', 'tflops': conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
+                        'peak_fp32_mfma_tflops': 157.3, 'kernel_ms_per_step': conv_ms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(args.config)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -32,6 +32,13 @@ extern "C" {
 
 #define SG3_ABI_VERSION 1
 
+/* exported from libsg3hip.so (the library is built with -fvisibility=hidden) */
+#if defined(__GNUC__)
+#define SG3_API __attribute__((visibility("default")))
+#else
+#define SG3_API
+#endif
+
 enum {
     SG3_OK          =  0,
     SG3_NO_KERNEL   = -1,  /* no specialised kernel: caller uses the generic composition */
@@ -46,10 +53,10 @@ enum {
     SG3_F64 = 2,   /* bias_act / upfirdn2d / filtered_lrelu_act only */
 };
 
-int         sg3_abi_version(void);
-const char* sg3_last_error(void);
+SG3_API int         sg3_abi_version(void);
+SG3_API const char* sg3_last_error(void);
 /* number of HIP devices visible to the library (0 on a CPU-only host; never fails) */
-int         sg3_device_count(void);
+SG3_API int         sg3_device_count(void);
 
 /* ------------------------------------------------------------------------
  * filtered_lrelu  -- replaces filtered_lrelu_plugin.filtered_lrelu
@@ -96,17 +103,17 @@ typedef struct sg3_filtered_lrelu_params {
     int32_t        readSigns;
 } sg3_filtered_lrelu_params;
 
-int sg3_filtered_lrelu(const sg3_filtered_lrelu_params* p, void* stream);
+SG3_API int sg3_filtered_lrelu(const sg3_filtered_lrelu_params* p, void* stream);
 
 /* 1 when sg3_filtered_lrelu has a fused kernel for this tuple (host-only
  * query; mirrors the reference's choose_filtered_lrelu_kernel test call,
  * torch_utils/ops/filtered_lrelu.cpp:46-56). */
-int sg3_filtered_lrelu_has_kernel(int up, int down, int fuW, int fuH, int fdW, int fdH);
+SG3_API int sg3_filtered_lrelu_has_kernel(int up, int down, int fuW, int fuH, int fdW, int fdH);
 
 /* Output / sign-tensor geometry exactly as the reference host code derives it
  * (torch_utils/ops/filtered_lrelu.cpp:59-98).  Returns SG3_BAD_ARG when the
  * reference would raise.  Any out pointer may be NULL. */
-int sg3_filtered_lrelu_shape(int xH, int xW, int up, int down,
+SG3_API int sg3_filtered_lrelu_shape(int xH, int xW, int up, int down,
                              int fuW, int fuH, int fdW, int fdH,
                              int px0, int px1, int py0, int py1,
                              int* yH, int* yW,
@@ -131,7 +138,7 @@ typedef struct sg3_filtered_lrelu_act_params {
     int32_t        readSigns;
 } sg3_filtered_lrelu_act_params;
 
-int sg3_filtered_lrelu_act(const sg3_filtered_lrelu_act_params* p, void* stream);
+SG3_API int sg3_filtered_lrelu_act(const sg3_filtered_lrelu_act_params* p, void* stream);
 
 /* ------------------------------------------------------------------------
  * upfirdn2d  -- replaces upfirdn2d_plugin.upfirdn2d
@@ -156,9 +163,9 @@ typedef struct sg3_upfirdn2d_params {
     float          gain;
 } sg3_upfirdn2d_params;
 
-int sg3_upfirdn2d(const sg3_upfirdn2d_params* p, void* stream);
+SG3_API int sg3_upfirdn2d(const sg3_upfirdn2d_params* p, void* stream);
 
-int sg3_upfirdn2d_shape(int xH, int xW, int fH, int fW,
+SG3_API int sg3_upfirdn2d_shape(int xH, int xW, int fH, int fW,
                         int upx, int upy, int downx, int downy,
                         int padx0, int padx1, int pady0, int pady1,
                         int* yH, int* yW);
@@ -189,55 +196,46 @@ typedef struct sg3_bias_act_params {
     int32_t        stepB;
 } sg3_bias_act_params;
 
-int sg3_bias_act(const sg3_bias_act_params* p, void* stream);
+SG3_API int sg3_bias_act(const sg3_bias_act_params* p, void* stream);
 
 /* ------------------------------------------------------------------------
  * modulated_conv2d -- replaces the grouped F.conv2d behind
  *   models/stylegan3/networks_stylegan3.py:24-63 (modulated_conv2d), reached
  *   through torch_utils/ops/conv2d_gradfix.py:36-39.
  *
- *   out[n,o,:,:] = dcoef[n,o] * sum_{i,ky,kx} w[o,i,ky,kx] *
+ *   out[n,o,:,:] = dcoef[n,o] * sum_{i,ky,kx} wn[o,i,ky,kx] *
  *                  (x[n,i,:,:] * sIn[n,i]) (zero padded by `pad`)
  *
  * i.e. the per-sample modulation is applied to the INPUT channels and the
  * demodulation to the OUTPUT channels, so the whole batch shares one weight
  * matrix and runs as a single implicit GEMM (M = O, N = batch*pixels,
- * K = I*k*k) on the fp32 matrix cores.  The caller supplies
- *   w     [O,I,k,k] float32, already pre-normalised when demodulating,
- *   sIn   [N,I]     float32 = styles (pre-normalised) * input_gain,
- *   dcoef [N,O]     float32 demodulation coefficients, or NULL (ToRGB).
+ * K = I*k*k) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+ * Two calls:
+ *   sg3_modulated_conv2d_prep  -> wPacked, sIn, dcoef   (tiny)
+ *   sg3_modulated_conv2d       -> out
  * x / out are NCHW contiguous, dtype f32 or f16; accumulation is fp32.
- * outH = H + 2*pad - k + 1.
+ * outH = H + 2*pad - k + 1.  k is 1 or 3.
  * ---------------------------------------------------------------------- */
-typedef struct sg3_modconv_params {
-    const void*    x;          /* [N,I,H,W] */
-    const float*   w;          /* [O,I,k,k] */
-    const float*   sIn;        /* [N,I] */
-    const float*   dcoef;      /* [N,O] or NULL */
-    void*          out;        /* [N,O,outH,outW] */
-    int32_t        dtype;      /* SG3_F32 | SG3_F16 (x and out) */
-    int32_t        N, I, O, H, W;
-    int32_t        k;          /* 1 or 3 */
-    int32_t        pad;
-} sg3_modconv_params;
 
-int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream);
+/* number of floats of the packed weight buffer for an [O,I,k,k] weight
+ * (layout [O][ceil(I/KC)][k*k][KC], zero padded; KC depends on k). */
+SG3_API int64_t sg3_modconv_packed_floats(int O, int I, int k);
 
-/* Demodulation coefficients and input scales for sg3_modulated_conv2d
+/* Demodulation coefficients and input scales
  * (models/stylegan3/networks_stylegan3.py:39-56):
- *   wn    = w * rsqrt(mean(w^2 over I,k,k))          (per O)    -> wOut [O,I,k,k]
+ *   wn    = w * rsqrt(mean(w^2 over I,k,k))          (per O)    -> wPacked
  *   sn    = s * rsqrt(mean(s^2 over N,I))
  *   dcoef = rsqrt( sum_{i,k} (wn[o,i,k] * sn[n,i])^2 + 1e-8 )   -> dcoef [N,O]
  *   sIn   = sn * inputGain                                      -> sIn [N,I]
- * With demodulate == 0: wOut = w, sIn = s * inputGain, dcoef untouched.
+ * With demodulate == 0: wn = w, sn = s, dcoef is not written.
  * inputGain is a DEVICE pointer (it derives from the magnitude_ema buffer,
  * :344) read according to inputGainMode: 0 none, 1 one scalar, 2 [I], 3 [N,I].
- * `wsq` is scratch [O,I] float32.
+ * `wsq` is scratch [O,I] float32 (per-(o,i) sum over taps of wn^2).
  * ---------------------------------------------------------------------- */
 typedef struct sg3_modconv_prep_params {
     const float*   w;          /* [O,I,k,k] */
     const float*   s;          /* [N,I] */
-    float*         wOut;       /* [O,I,k,k] */
+    float*         wPacked;    /* sg3_modconv_packed_floats(O,I,k) floats */
     float*         wsq;        /* [O,I] scratch */
     float*         sIn;        /* [N,I] */
     float*         dcoef;      /* [N,O] (NULL allowed when demodulate == 0) */
@@ -247,7 +245,21 @@ typedef struct sg3_modconv_prep_params {
     int32_t        demodulate;
 } sg3_modconv_prep_params;
 
-int sg3_modulated_conv2d_prep(const sg3_modconv_prep_params* p, void* stream);
+SG3_API int sg3_modulated_conv2d_prep(const sg3_modconv_prep_params* p, void* stream);
+
+typedef struct sg3_modconv_params {
+    const void*    x;          /* [N,I,H,W] */
+    const float*   wPacked;    /* from sg3_modulated_conv2d_prep */
+    const float*   sIn;        /* [N,I] */
+    const float*   dcoef;      /* [N,O] or NULL (no demodulation) */
+    void*          out;        /* [N,O,outH,outW] */
+    int32_t        dtype;      /* SG3_F32 | SG3_F16 (x and out) */
+    int32_t        N, I, O, H, W;
+    int32_t        k;          /* 1 or 3 */
+    int32_t        pad;
+} sg3_modconv_params;
+
+SG3_API int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,442 @@
+// sg3_filtered_lrelu.hip -- fused bias -> upsample FIR -> gain*lrelu -> clamp -> downsample FIR for gfx950.
+//
+// Replaces filtered_lrelu_plugin.filtered_lrelu (reference torch_utils/ops/filtered_lrelu.cpp:16-209 and the
+// tile kernel torch_utils/ops/filtered_lrelu.cu:139-1099).  The reference kernel is a CUDA thread-block tile
+// pipeline (input tile -> 4 shared-memory passes, 512-1024 threads, warp-32 sign packing).  This one is built
+// for CDNA4 from scratch around two observations:
+//
+//   * the op is on the fp32 VALU / HBM ridge (~21 FLOP/B), so the design goal is "nothing but FMAs
+//     in the instruction stream": no halo recompute in the vertical direction, no LDS operand per FMA, no
+//     workgroup barriers;
+//   * both vertical FIR passes and the non-linearity are column-local, so they can live entirely in registers.
+//
+// Kernel `flrelu_stream_kernel` -- ONE WAVE (64 lanes) owns a strip of up to 120 output columns of one (n,c)
+// plane and streams down a chunk of output rows:
+//
+//     global row i  --(+bias, zero outside the image)-->  LDS row  --H-up (polyphase, taps in SGPRs)-->
+//     4 upsampled columns per lane, kept as a 6-row sliding window in VGPRs
+//       --V-up (polyphase) --> U new upsampled rows in registers --> *gain, lrelu, clamp
+//       --V-down: every upsampled row is scattered into 6 rotating accumulators (FD/D output rows in flight)
+//     completed accumulator row --> LDS row --H-down (even/odd polyphase, ds_read_b64 pairs)--> global store
+//
+//   Per input row and lane that is 1 LDS row write + 8 LDS dword reads + 4 LDS writes + 24 LDS dword reads
+//   against ~100 (U=2) / ~190 (U=4) VALU FMAs; the only data that ever touches LDS is one input row and one
+//   output row, and because a wave only talks to itself there is no s_barrier anywhere (LDS executes a wave's
+//   DS instructions in order; the compiler is held back with wavefront-scope fences).  The window / accumulator
+//   rotation is resolved at compile time by unrolling 6 input rows per loop iteration.
+//   Global reads are issued 6 rows ahead into registers; reads and writes are 256-B contiguous per instruction.
+//   Grid = planes x row-chunks x strips, renumbered so that blocks sharing halo columns/rows sit on one XCD (L2).
+//
+// Supported by the streaming kernel (everything the StyleGAN3 forward needs): separable fu/fd with
+// (up, down, fuTaps, fdTaps) in {(2,2,12,12), (4,2,24,12)}, fp32 / fp16 I/O, unit innermost stride, no sign
+// tensor.  `flrelu_pointwise_kernel` covers up = down = 1 with 1x1 filters (the ToRGB layer).  Anything else
+// (2-D radial filters of config R, sign write/read for backward, other factors) returns SG3_NO_KERNEL and the
+// caller composes upfirdn2d + filtered_lrelu_act + upfirdn2d, exactly like the reference's rc = -1 path.
+//
+// Algorithmic traffic: C*(xH*xW + yH*yW)*sizeof(T) bytes per image -- the roofline figure bench.py uses.
+#include "sg3_common.h"
+#include <cmath>
+
+namespace sg3 {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct StreamParams {
+    const void* x; void* y; const void* b; const float* fu; const float* fd;
+    int C, xH, xW, yH, yW;
+    long long xsN, xsC, xsH;      // element strides (innermost stride is 1)
+    long long ysN, ysC, ysH;
+    long long bStride;
+    int px0, py0;
+    int TW;                        // output columns per strip (<= 120)
+    int CH;                        // output rows per chunk
+    int nStrips, nChunks;
+    int totalBlocks;
+    float gain, slope, clamp;
+    int flip;
+};
+
+__device__ __forceinline__ float to_sgpr(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// Compiler-level ordering of this wave's LDS traffic (no instruction is emitted: a wave's DS ops execute in order).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
+
+template <int U, int D> struct StreamCfg {
+    static constexpr int FU = 6 * U, FD = 6 * D;
+    static constexpr int CPL = 4;                       // upsampled columns per lane
+    static constexpr int GROUPS = CPL / U;              // column groups per lane that share one input window
+    static constexpr int IWS = GROUPS * 64 + 6;         // input samples a wave needs per row (+ slack)
+    static constexpr int NL = (IWS + 63) / 64;          // global loads per lane per row
+    static constexpr int SIN = NL * 64;                 // LDS floats for the input row
+    static constexpr int SOUT = 4 + 256 + 16;           // LDS floats for the output row
+    static constexpr int OPL = 2;                       // outputs per lane per row (lane l -> columns l and l+64)
+    static constexpr int MAXTW = 120;
+};
+
+template <typename T, int U, int D>
+struct WaveState {
+    typedef StreamCfg<U, D> Cfg;
+    v2f w[6][2];                  // sliding window of H-upsampled rows: [slot][column pair]
+    v2f acc[6][2];                // output rows in flight: [slot][column pair]
+    float pre[6][Cfg::NL];        // prefetched input samples for the next 6 rows
+    float tu[Cfg::FU];            // horizontal up taps (x U)
+    float tv[Cfg::FU];            // vertical up taps (x U x gain)
+    float td[Cfg::FD];            // down taps
+};
+
+template <typename T, int U, int D, int VPH>
+struct Stream {
+    typedef StreamCfg<U, D> Cfg;
+    typedef WaveState<T, U, D> State;
+
+    // issue the global loads of input row `i` into st.pre[slot]
+    static __device__ __forceinline__ void prefetch(State& st, int slot, const StreamParams& p, const T* __restrict__ plane,
+                                                    int i, int ibase, int lane, float bias) {
+        const bool rowOk = (unsigned)i < (unsigned)p.xH;
+        const T* row = plane + (long long)i * p.xsH;
+#pragma unroll
+        for (int q = 0; q < Cfg::NL; q++) {
+            const int ix = ibase + lane + 64 * q;
+            float v = 0.f;
+            if (rowOk && (unsigned)ix < (unsigned)p.xW) v = io<T>::ld(row + ix) + bias;
+            st.pre[slot][q] = v;
+        }
+    }
+
+    // one input row: H-up into window slot S, then U upsampled rows through lrelu into the down accumulators
+    template <int S, int HEAD>
+    static __device__ __forceinline__ void step(State& st, const StreamParams& p, const T* __restrict__ plane, T* __restrict__ oplane,
+                                                float* sIn, float* sOut, int i, int ibase, int delta, int lane, float bias,
+                                                int oy0, int oy1, int ox0, int oxN) {
+        // ---- input row -> LDS -> this lane's H-upsampled samples ----
+        wave_lds_sync();                 // the previous row's sIn reads precede this row's writes
+#pragma unroll
+        for (int q = 0; q < Cfg::NL; q++) sIn[lane + 64 * q] = st.pre[S][q];
+        prefetch(st, S, p, plane, i + 6, ibase, lane, bias);
+        wave_lds_sync();
+        if (U == 2) {
+            float xs[8];
+            const v2f* src = reinterpret_cast<const v2f*>(sIn + 2 * lane);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { v2f t = src[q]; xs[2 * q] = t.x; xs[2 * q + 1] = t.y; }
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                v2f a = splat(0.f);
+#pragma unroll
+                for (int t = 0; t < 6; t++) a = fma2(splat(xs[g + t]), (v2f){st.tu[2 * t + 1], st.tu[2 * t]}, a);
+                st.w[S][g] = a;
+            }
+        } else {  // U == 4: the lane's four columns are the four phases of one input window
+            float xs[6];
+#pragma unroll
+            for (int t = 0; t < 6; t++) xs[t] = sIn[lane + t];
+            v2f a0 = splat(0.f), a1 = splat(0.f);
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+                a0 = fma2(splat(xs[t]), (v2f){st.tu[4 * t + 3], st.tu[4 * t + 2]}, a0);
+                a1 = fma2(splat(xs[t]), (v2f){st.tu[4 * t + 1], st.tu[4 * t + 0]}, a1);
+            }
+            st.w[S][0] = a0; st.w[S][1] = a1;
+        }
+        // ---- U new upsampled rows ----
+        const float slope = p.slope, clampv = p.clamp;
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int kv = U - 1 - j;                          // vertical up phase of this row
+            v2f u0 = splat(0.f), u1 = splat(0.f);
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+                const int slot = (S + 1 + t) % 6;              // t = 0: oldest row (i - 5)
+                const v2f tap = splat(st.tv[kv + U * t]);
+                u0 = fma2(st.w[slot][0], tap, u0);
+                u1 = fma2(st.w[slot][1], tap, u1);
+            }
+            // leaky ReLU (gain already folded into tv; slope <= 1 so lrelu(v) = max(v, slope*v)) and clamp
+            const v2f s0 = u0 * splat(slope), s1 = u1 * splat(slope);
+            float a[4] = {__builtin_fmaxf(u0.x, s0.x), __builtin_fmaxf(u0.y, s0.y), __builtin_fmaxf(u1.x, s1.x), __builtin_fmaxf(u1.y, s1.y)};
+#pragma unroll
+            for (int c = 0; c < 4; c++) a[c] = __builtin_amdgcn_fmed3f(a[c], -clampv, clampv);
+            const v2f r0 = {a[0], a[1]}, r1 = {a[2], a[3]};
+            // scatter into the FD/D output rows this upsampled row belongs to
+            const int kp = (VPH + j) % D;                      // down phase of this row
+            const int headNow = (HEAD + ((VPH + j) / D)) % 6;  // completions so far in this step shift the head
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const int slot = (headNow + 5 - r) % 6;        // r = 5: oldest output row (completes first)
+                const v2f tap = splat(st.td[kp + r * D]);
+                st.acc[slot][0] = fma2(r0, tap, st.acc[slot][0]);
+                st.acc[slot][1] = fma2(r1, tap, st.acc[slot][1]);
+            }
+            if (kp == D - 1) {
+                // output row complete: H-down through LDS and store
+                const int uy = U * (i - 5) - (U - 1) + j + p.py0;
+                const int oy = (uy - (Cfg::FD - 1)) / D;       // exact
+                const v2f o0 = st.acc[headNow][0], o1 = st.acc[headNow][1];
+                st.acc[headNow][0] = splat(0.f); st.acc[headNow][1] = splat(0.f);
+                if (oy >= oy0 && oy < oy1) {                   // wave-uniform
+                    float* dst = sOut + (4 - delta) + 4 * lane;
+                    dst[0] = o0.x; dst[1] = o0.y; dst[2] = o1.x; dst[3] = o1.y;
+                    wave_lds_sync();
+                    T* orow = oplane + (long long)oy * p.ysH + ox0;
+#pragma unroll
+                    for (int o = 0; o < Cfg::OPL; o++) {
+                        const v2f* src = reinterpret_cast<const v2f*>(sOut + 4 + D * (lane + 64 * o));
+                        v2f s = splat(0.f);
+#pragma unroll
+                        for (int q = 0; q < Cfg::FD / 2; q++) s = fma2(src[q], (v2f){st.td[2 * q], st.td[2 * q + 1]}, s);
+                        const int col = lane + 64 * o;
+                        if (col < oxN) io<T>::st(orow + col, s.x + s.y);
+                    }
+                    wave_lds_sync();
+                }
+            }
+        }
+    }
+
+    static __device__ __forceinline__ void run(const StreamParams& p) {
+        static_assert(U % D == 0 && D == 2, "streaming kernel: down must be 2 and divide up");
+        __shared__ __attribute__((aligned(16))) float lds[Cfg::SIN + Cfg::SOUT];
+        float* sIn = lds;
+        float* sOut = lds + Cfg::SIN;
+        const int lane = threadIdx.x;
+
+        // XCD-aware renumbering: consecutive logical blocks (adjacent strips / chunks of one plane) share an XCD's L2
+        int bid = blockIdx.x;
+        {
+            const int nb = p.totalBlocks, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        }
+        const int strip = bid % p.nStrips;
+        const int chunk = (bid / p.nStrips) % p.nChunks;
+        const int plane_id = bid / (p.nStrips * p.nChunks);
+        const int n = plane_id / p.C, c = plane_id - n * p.C;
+
+        const int ox0 = strip * p.TW;
+        const int oxN = min(p.TW, p.yW - ox0);
+        const int oy0 = chunk * p.CH;
+        const int oy1 = min(oy0 + p.CH, p.yH);
+
+        const T* plane = (const T*)p.x + (long long)n * p.xsN + (long long)c * p.xsC;
+        T* oplane = (T*)p.y + (long long)n * p.ysN + (long long)c * p.ysC;
+        const float bias = io<T>::ld((const T*)p.b + (long long)c * p.bStride);
+
+        State st;
+        // taps -> scalar registers; effective correlation taps g[k] = f[flip ? k : taps-1-k]
+        const float gU = (float)U, gV = (float)U * p.gain;
+#pragma unroll
+        for (int k = 0; k < Cfg::FU; k++) {
+            const float f = p.fu[p.flip ? k : Cfg::FU - 1 - k];
+            st.tu[k] = to_sgpr(f * gU);
+            st.tv[k] = to_sgpr(f * gV);
+        }
+#pragma unroll
+        for (int k = 0; k < Cfg::FD; k++) st.td[k] = to_sgpr(p.fd[p.flip ? k : Cfg::FD - 1 - k]);
+
+        // horizontal geometry: first upsampled column of the strip, shifted left by delta so that every lane's
+        // U-column groups start at an upsampled position == 1 (mod U) and share one input window
+        const int delta = ((D * ox0 - p.px0 - 1) % U + U) % U;
+        const int uxs = D * ox0 - delta;
+        const int ibase = floor_div(uxs - p.px0 - 1, U) + 1;
+
+        // vertical geometry
+        const int uyA = oy0 * D;
+        const int uyB = (oy1 - 1) * D + Cfg::FD - 1;
+        const int iFirst = ceil_div_s(uyA - p.py0, U);          // first input row of the window that yields uyA
+        const int iLast = ceil_div_s(uyB - p.py0, U) + 5;       // step that yields uyB
+        const int nBlocks = (iLast - iFirst + 1 + 5) / 6;
+
+#pragma unroll
+        for (int s = 0; s < 6; s++) {
+            st.w[s][0] = splat(0.f); st.w[s][1] = splat(0.f);
+            st.acc[s][0] = splat(0.f); st.acc[s][1] = splat(0.f);
+            prefetch(st, s, p, plane, iFirst + s, ibase, lane, bias);
+        }
+
+        constexpr int ADV = U / D;                               // output rows completed per input row
+        int i = iFirst;
+        for (int blk = 0; blk < nBlocks; blk++, i += 6) {
+            step<0, (0 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 0, ibase, delta, lane, bias, oy0, oy1, ox0, oxN);
+            step<1, (1 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 1, ibase, delta, lane, bias, oy0, oy1, ox0, oxN);
+            step<2, (2 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 2, ibase, delta, lane, bias, oy0, oy1, ox0, oxN);
+            step<3, (3 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 3, ibase, delta, lane, bias, oy0, oy1, ox0, oxN);
+            step<4, (4 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 4, ibase, delta, lane, bias, oy0, oy1, ox0, oxN);
+            step<5, (5 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 5, ibase, delta, lane, bias, oy0, oy1, ox0, oxN);
+        }
+    }
+};
+
+template <typename T, int U, int D, int VPH>
+__global__ void __launch_bounds__(64)
+flrelu_stream_kernel(StreamParams p) {
+    Stream<T, U, D, VPH>::run(p);
+}
+
+// ---------------------------------------------------------------------------
+// up = down = 1, 1x1 filters: y = clamp(lrelu((x + b) * fu * gain)) * fd   (ToRGB layer: clamp(x + b))
+struct PointParams {
+    const void* x; void* y; const void* b;
+    const float* fu; const float* fd;
+    int N, C, H, W;
+    long long xs[4], ys[4], bStride;
+    int px0, py0, yH, yW;
+    float gain, slope, clamp;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+flrelu_pointwise_kernel(PointParams p) {
+    const float fu = p.fu[0], fd = p.fd[0];
+    const long long total = (long long)p.N * p.C * p.yH * p.yW;
+    const long long gs = (long long)gridDim.x * blockDim.x;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int ox = (int)(idx % p.yW); long long t = idx / p.yW;
+        const int oy = (int)(t % p.yH); t /= p.yH;
+        const int c = (int)(t % p.C); const int n = (int)(t / p.C);
+        const int ix = ox - p.px0, iy = oy - p.py0;
+        float v = 0.f;
+        if ((unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H)
+            v = io<T>::ld((const T*)p.x + n * p.xs[0] + c * p.xs[1] + iy * p.xs[2] + ix * p.xs[3]) + io<T>::ld((const T*)p.b + c * p.bStride);
+        v *= fu * p.gain;
+        v = v < 0.f ? v * p.slope : v;
+        v = fminf(fmaxf(v, -p.clamp), p.clamp);
+        io<T>::st((T*)p.y + n * p.ys[0] + c * p.ys[1] + oy * p.ys[2] + ox * p.ys[3], v * fd);
+    }
+}
+
+// ---------------------------------------------------------------------------
+static bool stream_supported(int up, int down, int fuW, int fuH, int fdW, int fdH) {
+    if (fuH != 0 || fdH != 0) return false;                   // separable only
+    if (down != 2 || fdW != 12) return false;
+    return (up == 2 && fuW == 12) || (up == 4 && fuW == 24);
+}
+
+// the streaming kernel evaluates lrelu as max(v, slope * v), valid for 0 <= slope <= 1 (every StyleGAN3 layer)
+static bool stream_params_ok(const sg3_filtered_lrelu_params& q) {
+    return q.slope >= 0.f && q.slope <= 1.f && q.xStride[3] == 1 && q.yStride[3] == 1 && !(q.clamp < 0.f);
+}
+
+static bool pointwise_supported(int up, int down, int fuW, int fuH, int fdW, int fdH) {
+    return up == 1 && down == 1 && fuW == 1 && fdW == 1 && fuH <= 1 && fdH <= 1;
+}
+
+template <typename T>
+static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
+    StreamParams p;
+    p.x = q.x; p.y = q.y; p.b = q.b; p.fu = q.fu; p.fd = q.fd;
+    p.C = q.C; p.xH = q.xH; p.xW = q.xW; p.yH = q.yH; p.yW = q.yW;
+    p.xsN = q.xStride[0]; p.xsC = q.xStride[1]; p.xsH = q.xStride[2];
+    p.ysN = q.yStride[0]; p.ysC = q.yStride[1]; p.ysH = q.yStride[2];
+    p.bStride = q.bStride;
+    p.px0 = q.px0; p.py0 = q.py0;
+    p.gain = q.gain; p.slope = q.slope; p.clamp = q.clamp; p.flip = q.flip;
+
+    // strips: equal widths <= 120 columns
+    const int maxTW = 120;
+    p.nStrips = ceil_div(q.yW, maxTW);
+    p.TW = ceil_div(q.yW, p.nStrips);
+    // row chunks: enough waves to fill 256 CUs x 16 waves a few times over, but chunks tall enough that the
+    // 11-row warm-up stays small
+    const long long planes = (long long)q.N * q.C;
+    const long long wantWaves = 256LL * 16 * 4;
+    int nChunks = (int)ceil_div64(wantWaves, planes * p.nStrips);
+    const int maxChunks = max(1, q.yH / 48);
+    if (nChunks > maxChunks) nChunks = maxChunks;
+    if (nChunks < 1) nChunks = 1;
+    p.CH = ceil_div(q.yH, nChunks);
+    p.nChunks = ceil_div(q.yH, p.CH);
+    const long long total = planes * p.nStrips * p.nChunks;
+    if (total > 0x7fffffffLL) { set_error("filtered_lrelu: grid too large"); return SG3_BAD_ARG; }
+    p.totalBlocks = (int)total;
+
+    const int vph = (((q.py0 - (q.up - 1)) % q.down) + q.down) % q.down;
+    dim3 g((unsigned)total), b(64);
+#define SG3_STREAM_LAUNCH(U, V) hipLaunchKernelGGL((flrelu_stream_kernel<T, U, 2, V>), g, b, 0, st, p)
+    if (q.up == 2) { if (vph == 0) SG3_STREAM_LAUNCH(2, 0); else SG3_STREAM_LAUNCH(2, 1); }
+    else           { if (vph == 0) SG3_STREAM_LAUNCH(4, 0); else SG3_STREAM_LAUNCH(4, 1); }
+#undef SG3_STREAM_LAUNCH
+    SG3_LAUNCH_CHECK("flrelu_stream_kernel");
+    return SG3_OK;
+}
+
+template <typename T>
+static int launch_pointwise(const sg3_filtered_lrelu_params& q, hipStream_t st) {
+    PointParams p;
+    p.x = q.x; p.y = q.y; p.b = q.b; p.fu = q.fu; p.fd = q.fd;
+    p.N = q.N; p.C = q.C; p.H = q.xH; p.W = q.xW; p.yH = q.yH; p.yW = q.yW;
+    for (int i = 0; i < 4; i++) { p.xs[i] = q.xStride[i]; p.ys[i] = q.yStride[i]; }
+    p.bStride = q.bStride; p.px0 = q.px0; p.py0 = q.py0;
+    p.gain = q.gain; p.slope = q.slope; p.clamp = q.clamp;
+    const long long total = (long long)q.N * q.C * q.yH * q.yW;
+    long long blocks = ceil_div64(total, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL((flrelu_pointwise_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    SG3_LAUNCH_CHECK("flrelu_pointwise_kernel");
+    return SG3_OK;
+}
+
+} // namespace sg3
+
+extern "C" {
+
+int sg3_filtered_lrelu_has_kernel(int up, int down, int fuW, int fuH, int fdW, int fdH) {
+    return (sg3::stream_supported(up, down, fuW, fuH, fdW, fdH) || sg3::pointwise_supported(up, down, fuW, fuH, fdW, fdH)) ? 1 : 0;
+}
+
+int sg3_filtered_lrelu_shape(int xH, int xW, int up, int down, int fuW, int fuH, int fdW, int fdH,
+                             int px0, int px1, int py0, int py1, int* yH, int* yW, int* sH, int* sWbytes, int* swLimit) {
+    using namespace sg3;
+    SG3_REQUIRE(xH > 0 && xW > 0, "x is empty");
+    SG3_REQUIRE(up >= 1 && down >= 1, "up and down must be at least 1");
+    SG3_REQUIRE(fuW >= 1 && fdW >= 1, "fu and fd must not be empty");
+    // separable filters have the same extent along both axes (reference :63-66 uses size(0) for the height)
+    const int64_t fut_w = fuW - 1, fut_h = (fuH ? fuH : fuW) - 1;
+    const int64_t fdt_w = fdW - 1, fdt_h = (fdH ? fdH : fdW) - 1;
+    const int64_t cw = (int64_t)xW * up + (px0 + px1) - fut_w;
+    const int64_t ch = (int64_t)xH * up + (py0 + py1) - fut_h;
+    SG3_REQUIRE(cw > fdt_w && ch > fdt_h, "upsampled buffer must be at least the size of downsampling filter");
+    SG3_REQUIRE(cw <= INT32_MAX && ch <= INT32_MAX, "upsampled buffer is too large");
+    const int64_t ow = (cw - fdt_w + (down - 1)) / down;
+    const int64_t oh = (ch - fdt_h + (down - 1)) / down;
+    SG3_REQUIRE(ow > 0 && oh > 0, "output must be at least 1x1");
+    const int64_t sw_active = ow * down - (down - 1) + fdt_w;
+    const int64_t sh = oh * down - (down - 1) + fdt_h;
+    const int64_t sw = (sw_active + 15) & ~(int64_t)15;
+    SG3_REQUIRE(sh <= INT32_MAX && (sw >> 2) <= INT32_MAX, "signs is too large");
+    if (yH) *yH = (int)oh;
+    if (yW) *yW = (int)ow;
+    if (sH) *sH = (int)sh;
+    if (sWbytes) *sWbytes = (int)(sw >> 2);
+    if (swLimit) *swLimit = (int)((sw_active + 3) >> 2);
+    return SG3_OK;
+}
+
+int sg3_filtered_lrelu(const sg3_filtered_lrelu_params* p, void* stream) {
+    using namespace sg3;
+    SG3_REQUIRE(p && p->x && p->y && p->b && p->fu && p->fd, "filtered_lrelu: null tensor");
+    SG3_REQUIRE(p->N > 0 && p->C > 0 && p->xH > 0 && p->xW > 0, "filtered_lrelu: x is empty");
+    SG3_REQUIRE(p->yH > 0 && p->yW > 0, "filtered_lrelu: output must be at least 1x1");
+    SG3_REQUIRE(p->up >= 1 && p->down >= 1, "filtered_lrelu: up and down must be at least 1");
+    SG3_REQUIRE(p->dtype == SG3_F32 || p->dtype == SG3_F16, "filtered_lrelu: x must be float16 or float32");
+    SG3_REQUIRE(!(p->writeSigns && p->readSigns), "filtered_lrelu: cannot read and write signs in one call");
+    hipStream_t st = (hipStream_t)stream;
+    const bool signs = p->writeSigns || p->readSigns;
+    if (!signs && pointwise_supported(p->up, p->down, p->fuW, p->fuH, p->fdW, p->fdH))
+        return p->dtype == SG3_F32 ? launch_pointwise<float>(*p, st) : launch_pointwise<_Float16>(*p, st);
+    if (!signs && stream_supported(p->up, p->down, p->fuW, p->fuH, p->fdW, p->fdH) && stream_params_ok(*p))
+        return p->dtype == SG3_F32 ? launch_stream<float>(*p, st) : launch_stream<_Float16>(*p, st);
+    set_error("filtered_lrelu: no fused kernel for up=%d down=%d fu=%dx%d fd=%dx%d signs=%d", p->up, p->down,
+              p->fuW, p->fuH, p->fdW, p->fdH, (int)signs);
+    return SG3_NO_KERNEL;
+}
+
+} // extern "C"

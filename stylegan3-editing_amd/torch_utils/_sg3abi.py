@@ -50,12 +50,12 @@ class BiasActParams(ctypes.Structure):
 
 
 class ModconvParams(ctypes.Structure):
-    _fields_ = [('x', c_vp), ('w', c_vp), ('sIn', c_vp), ('dcoef', c_vp), ('out', c_vp), ('dtype', c_i32),
+    _fields_ = [('x', c_vp), ('wPacked', c_vp), ('sIn', c_vp), ('dcoef', c_vp), ('out', c_vp), ('dtype', c_i32),
                 ('N', c_i32), ('I', c_i32), ('O', c_i32), ('H', c_i32), ('W', c_i32), ('k', c_i32), ('pad', c_i32)]
 
 
 class ModconvPrepParams(ctypes.Structure):
-    _fields_ = [('w', c_vp), ('s', c_vp), ('wOut', c_vp), ('wsq', c_vp), ('sIn', c_vp), ('dcoef', c_vp),
+    _fields_ = [('w', c_vp), ('s', c_vp), ('wPacked', c_vp), ('wsq', c_vp), ('sIn', c_vp), ('dcoef', c_vp),
                 ('inputGain', c_vp), ('inputGainMode', c_i32),
                 ('N', c_i32), ('I', c_i32), ('O', c_i32), ('k', c_i32), ('demodulate', c_i32)]
 
@@ -72,6 +72,7 @@ EXPORTS = [
     ('sg3_upfirdn2d', ctypes.c_int, [ctypes.POINTER(Upfirdn2dParams), c_vp]),
     ('sg3_upfirdn2d_shape', ctypes.c_int, [ctypes.c_int] * 12 + [ctypes.POINTER(ctypes.c_int)] * 2),
     ('sg3_bias_act', ctypes.c_int, [ctypes.POINTER(BiasActParams), c_vp]),
+    ('sg3_modconv_packed_floats', ctypes.c_int64, [ctypes.c_int] * 3),
     ('sg3_modulated_conv2d', ctypes.c_int, [ctypes.POINTER(ModconvParams), c_vp]),
     ('sg3_modulated_conv2d_prep', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), c_vp]),
 ]

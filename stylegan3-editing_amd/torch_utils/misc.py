@@ -90,7 +90,8 @@ def copy_params_and_buffers(src_module, dst_module, require_all=False):
     for name, tensor in named_params_and_buffers(dst_module):
         assert (name in src) or (not require_all), f'{name} missing from source module'
         if name in src:
-            tensor.copy_(src[name].detach()).requires_grad_(tensor.requires_grad)
+            with torch.no_grad():
+                tensor.copy_(src[name].detach())
 
 
 def print_module_summary(module, inputs, max_nesting=3, skip_redundant=True):

@@ -63,7 +63,7 @@ def _launch(x, w, s, demodulate, padding, input_gain):
         else:
             gmode, g = 3, g.expand(n, ci).contiguous()
         gptr = g
-    wn = torch.empty_like(w32)
+    wn = torch.empty([int(lib.sg3_modconv_packed_floats(co, ci, k))], dtype=torch.float32, device=dev)
     wsq = torch.empty([co, ci], dtype=torch.float32, device=dev)
     s_in = torch.empty([n, ci], dtype=torch.float32, device=dev)
     dcoef = torch.empty([n, co], dtype=torch.float32, device=dev) if demodulate else None
@@ -72,12 +72,12 @@ def _launch(x, w, s, demodulate, padding, input_gain):
     stream = abi.stream_ptr(dev)
     with torch.cuda.device(dev):
         pp = abi.ModconvPrepParams()
-        pp.w, pp.s, pp.wOut, pp.wsq, pp.sIn, pp.dcoef = abi.ptr(w32), abi.ptr(s32), abi.ptr(wn), abi.ptr(wsq), abi.ptr(s_in), abi.ptr(dcoef)
+        pp.w, pp.s, pp.wPacked, pp.wsq, pp.sIn, pp.dcoef = abi.ptr(w32), abi.ptr(s32), abi.ptr(wn), abi.ptr(wsq), abi.ptr(s_in), abi.ptr(dcoef)
         pp.inputGain, pp.inputGainMode = abi.ptr(gptr), gmode
         pp.N, pp.I, pp.O, pp.k, pp.demodulate = n, ci, co, k, int(bool(demodulate))
         abi.check(lib.sg3_modulated_conv2d_prep(ctypes.byref(pp), stream), 'sg3_modulated_conv2d_prep')
         cp = abi.ModconvParams()
-        cp.x, cp.w, cp.sIn, cp.dcoef, cp.out = abi.ptr(x), abi.ptr(wn), abi.ptr(s_in), abi.ptr(dcoef), abi.ptr(out)
+        cp.x, cp.wPacked, cp.sIn, cp.dcoef, cp.out = abi.ptr(x), abi.ptr(wn), abi.ptr(s_in), abi.ptr(dcoef), abi.ptr(out)
         cp.dtype = abi.dtype_code(x.dtype)
         cp.N, cp.I, cp.O, cp.H, cp.W, cp.k, cp.pad = n, ci, co, h, wd, k, int(padding)
         abi.check(lib.sg3_modulated_conv2d(ctypes.byref(cp), stream), 'sg3_modulated_conv2d')

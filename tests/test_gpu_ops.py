@@ -1,0 +1,258 @@
+"""GPU parity tests proper: every operator through the C ABI (libsg3hip.so) on a real MI355X against the golden
+vectors of the reference and against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp32 I/O, fp32 math; values are O(1)): 2e-5 max-abs for single ops; fp16 I/O: 4e-3 (one fp16 rounding
+of in/out).  BASELINE's end-to-end requirement is 1e-4 max-abs on the final image (test_gpu_net.py)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_cases import BIAS_ACT_CASES, FLRELU_CASES, FLRELU_GRAD_CASES, MODCONV_CASES, UPFIRDN_CASES, make_filter, rand
+from helpers import golden, maxabs, oracle_design, product_design
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def T(a, dtype=None):
+    if a is None:
+        return None
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def _flrelu(c, x, b, fu, fd, **kw):
+    from torch_utils.ops import filtered_lrelu
+    return filtered_lrelu.filtered_lrelu(x, fu=fu, fd=fd, b=b, up=c['up'], down=c['down'], padding=c['padding'], gain=c['gain'],
+                                         slope=c['slope'], clamp=c['clamp'], flip_filter=c['flip'], **kw)
+
+
+def test_library_loaded_and_launch_counter():
+    from torch_utils import _sg3abi
+    from torch_utils.ops import bias_act
+    n0 = _sg3abi.launch_count
+    bias_act.bias_act(torch.randn(4, 8, device=DEV), torch.randn(8, device=DEV), act='lrelu')
+    assert _sg3abi.launch_count == n0 + 1 and _sg3abi.load().sg3_device_count() >= 1
+
+
+@pytest.mark.parametrize('name', sorted(FLRELU_CASES))
+def test_filtered_lrelu_fp32(name):
+    c = FLRELU_CASES[name]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        y = _flrelu(c, T(rand(11, *c['shape'])), T(rand(12, c['shape'][1])) if c['bias'] else None,
+                    T(make_filter(c['fu'], product_design)), T(make_filter(c['fd'], product_design)))
+    ref = golden('ops')['flrelu/' + name]
+    assert tuple(y.shape) == ref.shape
+    assert maxabs(y.cpu().numpy(), ref) <= 2e-5
+
+
+@pytest.mark.parametrize('name', ['t_up2_dn2', 't_up4_dn2', 't_crit_l13', 't_torgb', 'r_up2_dnrad2'])
+def test_filtered_lrelu_fp16(name):
+    from oracle import oracle as O
+    c = FLRELU_CASES[name]
+    x16 = rand(11, *c['shape']).astype(np.float16); b16 = rand(12, c['shape'][1]).astype(np.float16)
+    fu, fd = make_filter(c['fu'], oracle_design), make_filter(c['fd'], oracle_design)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        y = _flrelu(c, T(x16), T(b16), T(fu), T(fd))
+    assert y.dtype == torch.float16
+    ref = O.filtered_lrelu(x16.astype(np.float32), fu, fd, b16.astype(np.float32), c['up'], c['down'], c['padding'], c['gain'], c['slope'], c['clamp'], c['flip'])
+    assert maxabs(y.float().cpu().numpy(), ref) <= 4e-3
+
+
+@pytest.mark.parametrize('shape,up,taps,pad', [
+    ((1, 2, 150, 150), 2, 12, [9, 8, 9, 8]),          # 2 strips (out 148), L6-like
+    ((2, 3, 86, 86), 4, 24, [-6, -9, -6, -9]),        # L5-like up4
+    ((1, 1, 278, 278), 4, 24, [-6, -9, -6, -9]),      # 5 strips, multiple row chunks
+    ((1, 2, 534, 300), 2, 12, [9, 8, 9, 8]),          # non-square, several chunks
+    ((1, 1, 130, 1046), 2, 12, [-11, -12, -11, -12]), # full-width critically sampled rows (9 strips)
+    ((3, 5, 38, 38), 2, 12, [9, 8, 9, 8]),
+])
+def test_filtered_lrelu_stream_kernel_sizes(shape, up, taps, pad):
+    """The streaming kernel across strip / chunk boundaries, against the oracle."""
+    from oracle import oracle as O
+    fs = 64
+    fu = O.design_lowpass_filter(taps, 4.0, 8.0, fs * up / 2)
+    fd = O.design_lowpass_filter(12, 5.0, 9.0, fs)
+    x = rand(3, *shape); b = rand(4, shape[1])
+    c = dict(up=up, down=2, padding=pad, gain=float(np.sqrt(2)), slope=0.2, clamp=256, flip=False)
+    y = _flrelu(c, T(x), T(b), T(fu), T(fd))
+    ref = O.filtered_lrelu(x, fu, fd, b, up, 2, pad, c['gain'], 0.2, 256, False)
+    assert tuple(y.shape) == ref.shape
+    assert maxabs(y.cpu().numpy(), ref) <= 2e-5
+
+
+def test_filtered_lrelu_strided_input_and_bias():
+    """Element strides are honoured (reference filtered_lrelu.cpp:127-134): channel-sliced and row-padded views."""
+    from oracle import oracle as O
+    c = FLRELU_CASES['t_up2_dn2']
+    fu, fd = make_filter(c['fu'], oracle_design), make_filter(c['fd'], oracle_design)
+    big = rand(5, 2, 6, 40, 44)
+    xv = T(big)[:, 1:4, 1:39, 3:41]                   # non-contiguous view, unit innermost stride
+    bv = T(rand(6, 6))[::2]                           # strided bias
+    y = _flrelu(c, xv, bv, T(fu), T(fd))
+    ref = O.filtered_lrelu(np.ascontiguousarray(big[:, 1:4, 1:39, 3:41]), fu, fd, rand(6, 6)[::2].copy(), 2, 2, c['padding'], c['gain'], 0.2, 256, False)
+    assert maxabs(y.cpu().numpy(), ref) <= 2e-5
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        ycl = _flrelu(c, xv.contiguous(memory_format=torch.channels_last), bv, T(fu), T(fd))   # generic path
+    assert maxabs(ycl.cpu().numpy(), ref) <= 2e-5
+
+
+@pytest.mark.parametrize('name', FLRELU_GRAD_CASES)
+def test_filtered_lrelu_backward(name):
+    """dx, db through the sign-tensor backward (forward writes 2-bit signs, backward = same op with up<->down)."""
+    c = FLRELU_CASES[name]
+    x = T(rand(11, *c['shape'])).requires_grad_(True)
+    b = T(rand(12, c['shape'][1])).requires_grad_(True) if c['bias'] else None
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        y = _flrelu(c, x, b, T(make_filter(c['fu'], product_design)), T(make_filter(c['fd'], product_design)))
+        (y * T(rand(13, *y.shape))).sum().backward()
+    g = golden('grads')
+    assert maxabs(y.detach().cpu().numpy(), golden('ops')['flrelu/' + name]) <= 2e-5
+    assert maxabs(x.grad.cpu().numpy(), g[name + '/dx']) <= 5e-5
+    if b is not None:
+        assert maxabs(b.grad.cpu().numpy(), g[name + '/db']) <= 2e-3
+
+
+def test_filtered_lrelu_act_signs_roundtrip():
+    """filtered_lrelu_act_: written signs reproduce the activation derivative when read back."""
+    from torch_utils.ops import filtered_lrelu
+    filtered_lrelu._init()
+    P = filtered_lrelu._plugin
+    x0 = T(rand(7, 2, 3, 9, 21) * 2)
+    x = x0.clone()
+    so = P.filtered_lrelu_act_(x, torch.empty(0), 0, 0, 1.5, 0.2, 1.0, True)
+    assert tuple(so.shape) == (2, 3, 9, 8) and so.dtype == torch.uint8
+    v = x0 * 1.5
+    ref = torch.where(v < 0, v * 0.2, v).clamp(-1, 1)
+    assert maxabs(x.cpu().numpy(), ref.cpu().numpy()) <= 1e-6
+    g = torch.ones_like(x0)
+    P.filtered_lrelu_act_(g, so, 0, 0, 1.5, 0.2, 1.0, False)
+    lin = torch.where(v < 0, torch.full_like(v, 0.2), torch.ones_like(v))
+    dref = torch.where(lin * v.abs() > 1.0, torch.zeros_like(v), 1.5 * lin)
+    assert maxabs(g.cpu().numpy(), dref.cpu().numpy()) <= 1e-6
+
+
+@pytest.mark.parametrize('name', sorted(UPFIRDN_CASES))
+def test_upfirdn2d(name):
+    from torch_utils.ops import upfirdn2d
+    c = UPFIRDN_CASES[name]
+    x = T(rand(21, *c['shape'])).requires_grad_(True)
+    y = upfirdn2d.upfirdn2d(x, T(make_filter(c['f'], product_design)), up=c['up'], down=c['down'], padding=c['padding'], flip_filter=c['flip'], gain=c['gain'])
+    assert maxabs(y.detach().cpu().numpy(), golden('ops')['upfirdn/' + name]) <= 1e-5
+    # adjoint test: <y, gy> gradient equals the ref path's gradient
+    gy = T(rand(22, *y.shape))
+    (y * gy).sum().backward()
+    xr = torch.from_numpy(rand(21, *c['shape'])).requires_grad_(True)
+    f = make_filter(c['f'], product_design)
+    yr = upfirdn2d.upfirdn2d(xr, None if f is None else torch.from_numpy(f), up=c['up'], down=c['down'], padding=c['padding'], flip_filter=c['flip'], gain=c['gain'])
+    (yr * gy.cpu()).sum().backward()
+    assert maxabs(x.grad.cpu().numpy(), xr.grad.numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.float64])
+def test_upfirdn2d_dtypes(dtype):
+    from torch_utils.ops import upfirdn2d
+    c = UPFIRDN_CASES['sep_up2']
+    x = torch.from_numpy(rand(21, *c['shape'])).to(dtype)
+    f = torch.from_numpy(make_filter(c['f'], product_design))
+    y = upfirdn2d.upfirdn2d(x.to(DEV), f.to(DEV), up=c['up'], down=c['down'], padding=c['padding'], gain=c['gain'])
+    ref = upfirdn2d.upfirdn2d(x.double(), f, up=c['up'], down=c['down'], padding=c['padding'], gain=c['gain'])
+    assert y.dtype == dtype
+    assert maxabs(y.double().cpu().numpy(), ref.numpy()) <= {torch.float32: 1e-5, torch.float16: 4e-3, torch.float64: 1e-6}[dtype]
+
+
+@pytest.mark.parametrize('name', sorted(BIAS_ACT_CASES))
+def test_bias_act(name):
+    from torch_utils.ops import bias_act
+    c = BIAS_ACT_CASES[name]
+    x = T(rand(31, *c['shape']) * 2); b = T(rand(32, c['shape'][c['dim']])) if c['bias'] else None
+    y = bias_act.bias_act(x, b, dim=c['dim'], act=c['act'], alpha=c['alpha'], gain=c['gain'], clamp=c['clamp'])
+    assert maxabs(y.cpu().numpy(), golden('ops')['bias_act/' + name]) <= 2e-6
+
+
+@pytest.mark.parametrize('act', ['linear', 'relu', 'lrelu', 'tanh', 'sigmoid', 'elu', 'selu', 'softplus', 'swish'])
+def test_bias_act_gradients(act):
+    """First and second order gradients of the HIP op equal autograd of the pure-PyTorch definition (fp64)."""
+    from torch_utils.ops import bias_act
+    xn, bn = rand(33, 5, 6, 4).astype(np.float64), rand(34, 6).astype(np.float64)
+    outs = []
+    for dev, impl in ((DEV, 'cuda'), ('cpu', 'ref')):
+        x = torch.from_numpy(xn).to(dev).requires_grad_(True); b = torch.from_numpy(bn).to(dev).requires_grad_(True)
+        y = bias_act.bias_act(x, b, dim=1, act=act, clamp=1.2, impl=impl)
+        gx, gb = torch.autograd.grad((y * y).sum(), [x, b], create_graph=True)
+        ggx, = torch.autograd.grad((gx * gx).sum() + (gb * gb).sum(), [x])
+        outs.append([t.detach().cpu().numpy() for t in (y, gx, gb, ggx)])
+    for a, r in zip(*outs):
+        assert maxabs(a, r) <= 1e-9 * max(1.0, float(np.abs(r).max()))
+
+
+@pytest.mark.parametrize('name', sorted(MODCONV_CASES))
+def test_modulated_conv2d(name):
+    from models.stylegan3.networks_stylegan3 import modulated_conv2d
+    c = MODCONV_CASES[name]
+    x = T(rand(41, c['n'], c['ci'], c['h'], c['w'])); w = T(rand(42, c['co'], c['ci'], c['k'], c['k'])); s = T(rand(43, c['n'], c['ci']) + 1)
+    ig = None if c['input_gain'] is None else torch.tensor(c['input_gain'], device=DEV)
+    y = modulated_conv2d(x, w, s, demodulate=c['demodulate'], padding=c['k'] - 1, input_gain=ig)
+    ref = golden('ops')['modconv/' + name]
+    assert tuple(y.shape) == ref.shape
+    assert maxabs(y.cpu().numpy(), ref) <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize('n,ci,co,h,k', [(2, 323, 203, 22, 3), (1, 128, 81, 40, 3), (2, 51, 32, 70, 3), (1, 32, 3, 64, 1), (2, 512, 512, 12, 3),
+                                         (2, 100, 161, 30, 1), (1, 64, 64, 33, 1)])
+def test_modulated_conv2d_sizes(n, ci, co, h, k):
+    """Odd channel counts / tile tails against the CPU oracle; also the [N,I] and [I] input-gain forms and padding 0."""
+    from oracle import oracle as O
+    from models.stylegan3.networks_stylegan3 import modulated_conv2d
+    x = rand(51, n, ci, h, h + 3); w = rand(52, co, ci, k, k); s = rand(53, n, ci) + 1
+    y = modulated_conv2d(T(x), T(w), T(s), demodulate=True, padding=k - 1, input_gain=torch.tensor(0.8, device=DEV))
+    ref = O.modulated_conv2d(x, w, s, True, k - 1, 0.8)
+    assert maxabs(y.cpu().numpy(), ref) <= 3e-5 * max(1.0, float(np.abs(ref).max()))
+    gvec = rand(54, ci) * 0.1 + 1
+    y2 = modulated_conv2d(T(x), T(w), T(s), demodulate=False, padding=0, input_gain=T(gvec))
+    ref2 = O.modulated_conv2d(x * gvec[None, :, None, None], w, s, False, 0, None)
+    assert maxabs(y2.cpu().numpy(), ref2) <= 3e-5 * max(1.0, float(np.abs(ref2).max()))
+
+
+def test_modulated_conv2d_fp16_and_grad():
+    from oracle import oracle as O
+    from models.stylegan3.networks_stylegan3 import modulated_conv2d
+    x = rand(61, 2, 24, 20, 20).astype(np.float16); w = rand(62, 16, 24, 3, 3); s = rand(63, 2, 24) + 1
+    y = modulated_conv2d(T(x), T(w), T(s), demodulate=True, padding=2, input_gain=torch.tensor(1.1, device=DEV))
+    assert y.dtype == torch.float16
+    ref = O.modulated_conv2d(x.astype(np.float32), w, s, True, 2, 1.1)
+    assert maxabs(y.float().cpu().numpy(), ref) <= 1e-2
+    # gradients w.r.t. x, w, s equal those of the composite formulation
+    from torch_utils.ops import modulated_conv as mc
+    res = []
+    for impl in ('cuda', 'ref'):
+        xs = T(rand(64, 2, 6, 9, 9)).requires_grad_(True); ws = T(rand(65, 5, 6, 3, 3)).requires_grad_(True); ss = (T(rand(66, 2, 6)) + 1).requires_grad_(True)
+        out = mc.modulated_conv2d(xs, ws, ss, demodulate=True, padding=2, input_gain=torch.tensor(0.9, device=DEV), impl=impl)
+        (out * T(rand(67, *out.shape))).sum().backward()
+        res.append([t.grad.cpu().numpy() for t in (xs, ws, ss)])
+    for a, r in zip(*res):
+        assert maxabs(a, r) <= 1e-4 * max(1.0, float(np.abs(r).max()))
+
+
+def test_error_behaviour():
+    """Argument errors surface as RuntimeError, like the reference's TORCH_CHECKs."""
+    from torch_utils.ops import filtered_lrelu
+    filtered_lrelu._init()
+    P = filtered_lrelu._plugin
+    x = torch.randn(1, 2, 8, 8, device=DEV); f = torch.ones(1, 1, device=DEV); b = torch.zeros(2, device=DEV)
+    with pytest.raises(RuntimeError, match='float32'):
+        P.filtered_lrelu(x, f.double(), f, b, torch.empty(0), 1, 1, 0, 0, 0, 0, 0, 0, 1.0, 0.2, 256.0, False, False)
+    with pytest.raises(RuntimeError, match='same dtype'):
+        P.filtered_lrelu(x, f, f, b.half(), torch.empty(0), 1, 1, 0, 0, 0, 0, 0, 0, 1.0, 0.2, 256.0, False, False)
+    with pytest.raises(RuntimeError, match='rank 4'):
+        P.filtered_lrelu(x[0], f, f, b, torch.empty(0), 1, 1, 0, 0, 0, 0, 0, 0, 1.0, 0.2, 256.0, False, False)
+    y, so, rc = P.filtered_lrelu(x, torch.ones(3, 3, device=DEV), f, b, torch.empty(0), 1, 1, 1, 1, 1, 1, 0, 0, 1.0, 0.2, 256.0, False, False)
+    assert rc == -1 and y.numel() == 0            # no fused kernel: the caller composes the generic path
