@@ -40,6 +40,10 @@
 namespace sg3 {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_f;          // explicit LDS address space: keeps ds_* instructions
+typedef __attribute__((address_space(3))) v2f lds_v2f;
+typedef __attribute__((address_space(3))) v4f lds_v4f;
 
 struct StreamParams {
     const void* x; void* y; const void* b; const float* fu; const float* fd;
@@ -70,6 +74,24 @@ __device__ __forceinline__ void wave_lds_sync() {
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
 
+// acc + a * tap, where the tap is ONE half of a scalar-register pair (two taps per SGPR pair, no duplicates).
+// The low half is expressible in C (the compiler emits op_sel_hi:[1,0,1]); the high half needs op_sel on the SGPR
+// source, which hipcc never selects (it copies the tap to a fresh pair instead and runs out of SGPRs), hence the asm.
+template <int HALF>
+__device__ __forceinline__ v2f fma_tap(v2f a, v2f tapPair, v2f acc) {
+    if (HALF == 0) return fma2(a, __builtin_shufflevector(tapPair, tapPair, 0, 0), acc);
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "s"(tapPair), "v"(acc));
+    return r;
+}
+template <int HALF>
+__device__ __forceinline__ v2f mul_tap(v2f a, v2f tapPair) {
+    if (HALF == 0) return a * __builtin_shufflevector(tapPair, tapPair, 0, 0);
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "s"(tapPair));
+    return r;
+}
+
 template <int U, int D> struct StreamCfg {
     static constexpr int FU = 6 * U, FD = 6 * D;
     static constexpr int CPL = 4;                       // upsampled columns per lane
@@ -78,8 +100,35 @@ template <int U, int D> struct StreamCfg {
     static constexpr int NL = (IWS + 63) / 64;          // global loads per lane per row
     static constexpr int SIN = NL * 64;                 // LDS floats for the input row
     static constexpr int SOUT = 4 + 256 + 16;           // LDS floats for the output row
-    static constexpr int OPL = 2;                       // outputs per lane per row (lane l -> columns l and l+64)
     static constexpr int MAXTW = 120;
+};
+
+// element <-> fp32 through raw buffer instructions: the hardware range check (offset >= num_records reads 0 /
+// drops the store) replaces every per-lane bounds branch
+template <typename T> struct bufio;
+template <> struct bufio<float> {
+    static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, int byteOff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byteOff, 0, 0));
+    }
+    static __device__ __forceinline__ void st1(__amdgpu_buffer_rsrc_t r, int byteOff, float v) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byteOff, 0, 0);
+    }
+    static __device__ __forceinline__ void st2(__amdgpu_buffer_rsrc_t r, int byteOff, float a, float b) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64((u2){__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)}, r, byteOff, 0, 0);
+    }
+};
+template <> struct bufio<_Float16> {
+    static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, int byteOff) {
+        return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, byteOff, 0, 0));
+    }
+    static __device__ __forceinline__ void st1(__amdgpu_buffer_rsrc_t r, int byteOff, float v) {
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), r, byteOff, 0, 0);
+    }
+    static __device__ __forceinline__ void st2(__amdgpu_buffer_rsrc_t r, int byteOff, float a, float b) {
+        const unsigned lo = __builtin_bit_cast(unsigned short, (_Float16)a), hi = __builtin_bit_cast(unsigned short, (_Float16)b);
+        __builtin_amdgcn_raw_buffer_store_b32(lo | (hi << 16), r, byteOff, 0, 0);
+    }
 };
 
 template <typename T, int U, int D>
@@ -87,10 +136,12 @@ struct WaveState {
     typedef StreamCfg<U, D> Cfg;
     v2f w[6][2];                  // sliding window of H-upsampled rows: [slot][column pair]
     v2f acc[6][2];                // output rows in flight: [slot][column pair]
-    float pre[6][Cfg::NL];        // prefetched input samples for the next 6 rows
-    float tu[Cfg::FU];            // horizontal up taps (x U)
-    float tv[Cfg::FU];            // vertical up taps (x U x gain)
-    float td[Cfg::FD];            // down taps
+    float pre[6][Cfg::NL];        // prefetched input samples (+bias) for the next 6 rows
+    float bcol[Cfg::NL];          // bias where this lane's input column exists, else 0
+    int coff[Cfg::NL];            // byte offset of this lane's input columns inside a row
+    v2f tuP[Cfg::FU / 2];         // up taps (x U) in REVERSED pairs (tu[2m+1], tu[2m]): the H-up column-pair operands
+                                  // as they stand, and the source of the V-up tap splats (odd tap = low half)
+    v2f tdP[Cfg::FD / 2];         // down taps (td[2m], td[2m+1]): V-down splats and H-down even/odd pairs
 };
 
 template <typename T, int U, int D, int VPH>
@@ -98,70 +149,78 @@ struct Stream {
     typedef StreamCfg<U, D> Cfg;
     typedef WaveState<T, U, D> State;
 
-    // issue the global loads of input row `i` into st.pre[slot]
-    static __device__ __forceinline__ void prefetch(State& st, int slot, const StreamParams& p, const T* __restrict__ plane,
-                                                    int i, int ibase, int lane, float bias) {
+    // issue the loads of input row `i` into st.pre[slot]; rows outside the image get a zero-length descriptor
+    static __device__ __forceinline__ void prefetch(State& st, int slot, const StreamParams& p, const T* __restrict__ plane, int i) {
         const bool rowOk = (unsigned)i < (unsigned)p.xH;
         const T* row = plane + (long long)i * p.xsH;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)row, (short)0, rowOk ? p.xW * (int)sizeof(T) : 0, 0x00020000);
+        const float rowFlag = rowOk ? 1.f : 0.f;
 #pragma unroll
-        for (int q = 0; q < Cfg::NL; q++) {
-            const int ix = ibase + lane + 64 * q;
-            float v = 0.f;
-            if (rowOk && (unsigned)ix < (unsigned)p.xW) v = io<T>::ld(row + ix) + bias;
-            st.pre[slot][q] = v;
-        }
+        for (int q = 0; q < Cfg::NL; q++)
+            st.pre[slot][q] = __builtin_fmaf(st.bcol[q], rowFlag, bufio<T>::ld(rs, st.coff[q]));
     }
 
     // one input row: H-up into window slot S, then U upsampled rows through lrelu into the down accumulators
     template <int S, int HEAD>
     static __device__ __forceinline__ void step(State& st, const StreamParams& p, const T* __restrict__ plane, T* __restrict__ oplane,
-                                                float* sIn, float* sOut, int i, int ibase, int delta, int lane, float bias,
-                                                int oy0, int oy1, int ox0, int oxN) {
+                                                lds_f* sIn, lds_f* sOut, int i, int delta, int lane,
+                                                int oy0, int oy1, int ox0, int oxN, bool pairStore) {
         // ---- input row -> LDS -> this lane's H-upsampled samples ----
         wave_lds_sync();                 // the previous row's sIn reads precede this row's writes
 #pragma unroll
         for (int q = 0; q < Cfg::NL; q++) sIn[lane + 64 * q] = st.pre[S][q];
-        prefetch(st, S, p, plane, i + 6, ibase, lane, bias);
+        prefetch(st, S, p, plane, i + 6);
         wave_lds_sync();
         if (U == 2) {
             float xs[8];
-            const v2f* src = reinterpret_cast<const v2f*>(sIn + 2 * lane);
+            // volatile: keeps four ds_read_b64 (2 LDS cycles each); merged into ds_read2_b64 they run at a quarter of that
+            const volatile lds_v2f* src = reinterpret_cast<const volatile lds_v2f*>(sIn + 2 * lane);
 #pragma unroll
             for (int q = 0; q < 4; q++) { v2f t = src[q]; xs[2 * q] = t.x; xs[2 * q + 1] = t.y; }
 #pragma unroll
             for (int g = 0; g < 2; g++) {
-                v2f a = splat(0.f);
+                v2f a = splat(xs[g]) * st.tuP[0];
 #pragma unroll
-                for (int t = 0; t < 6; t++) a = fma2(splat(xs[g + t]), (v2f){st.tu[2 * t + 1], st.tu[2 * t]}, a);
+                for (int t = 1; t < 6; t++) a = fma2(splat(xs[g + t]), st.tuP[t], a);
                 st.w[S][g] = a;
             }
         } else {  // U == 4: the lane's four columns are the four phases of one input window
             float xs[6];
 #pragma unroll
             for (int t = 0; t < 6; t++) xs[t] = sIn[lane + t];
-            v2f a0 = splat(0.f), a1 = splat(0.f);
+            v2f a0 = splat(xs[0]) * st.tuP[1], a1 = splat(xs[0]) * st.tuP[0];
 #pragma unroll
-            for (int t = 0; t < 6; t++) {
-                a0 = fma2(splat(xs[t]), (v2f){st.tu[4 * t + 3], st.tu[4 * t + 2]}, a0);
-                a1 = fma2(splat(xs[t]), (v2f){st.tu[4 * t + 1], st.tu[4 * t + 0]}, a1);
+            for (int t = 1; t < 6; t++) {
+                a0 = fma2(splat(xs[t]), st.tuP[2 * t + 1], a0);    // columns 0,1: phases 3,2
+                a1 = fma2(splat(xs[t]), st.tuP[2 * t], a1);        // columns 2,3: phases 1,0
             }
             st.w[S][0] = a0; st.w[S][1] = a1;
         }
         // ---- U new upsampled rows ----
-        const float slope = p.slope, clampv = p.clamp;
+        const float slope = p.slope, clampv = p.clamp / p.gain, gain = p.gain;
 #pragma unroll
         for (int j = 0; j < U; j++) {
-            constexpr int dummy = 0; (void)dummy;
             const int kv = U - 1 - j;                          // vertical up phase of this row
-            v2f u0 = splat(0.f), u1 = splat(0.f);
+            v2f u0, u1;
 #pragma unroll
             for (int t = 0; t < 6; t++) {
                 const int slot = (S + 1 + t) % 6;              // t = 0: oldest row (i - 5)
-                const v2f tap = splat(st.tv[kv + U * t]);
-                u0 = fma2(st.w[slot][0], tap, u0);
-                u1 = fma2(st.w[slot][1], tap, u1);
+                const int k = kv + U * t;
+                // tap k lives in the reversed pair k/2: odd k = low half, even k = high half
+                if (t == 0) {
+                    u0 = (k & 1) ? mul_tap<0>(st.w[slot][0], st.tuP[k / 2]) : mul_tap<1>(st.w[slot][0], st.tuP[k / 2]);
+                    u1 = (k & 1) ? mul_tap<0>(st.w[slot][1], st.tuP[k / 2]) : mul_tap<1>(st.w[slot][1], st.tuP[k / 2]);
+                } else if (k & 1) {
+                    u0 = fma_tap<0>(st.w[slot][0], st.tuP[k / 2], u0);
+                    u1 = fma_tap<0>(st.w[slot][1], st.tuP[k / 2], u1);
+                } else {
+                    u0 = fma_tap<1>(st.w[slot][0], st.tuP[k / 2], u0);
+                    u1 = fma_tap<1>(st.w[slot][1], st.tuP[k / 2], u1);
+                }
             }
-            // leaky ReLU (gain already folded into tv; slope <= 1 so lrelu(v) = max(v, slope*v)) and clamp
+            // leaky ReLU (slope <= 1 so lrelu(v) = max(v, slope*v)) and clamp.  The activation gain g > 0 commutes with
+            // both: clamp_c(lrelu(g*u)) = g * clamp_{c/g}(lrelu(u)), so g is applied once per OUTPUT sample after the
+            // down filter instead of once per upsampled sample (clampv = clamp / gain here)
             const v2f s0 = u0 * splat(slope), s1 = u1 * splat(slope);
             float a[4] = {__builtin_fmaxf(u0.x, s0.x), __builtin_fmaxf(u0.y, s0.y), __builtin_fmaxf(u1.x, s1.x), __builtin_fmaxf(u1.y, s1.y)};
 #pragma unroll
@@ -173,29 +232,43 @@ struct Stream {
 #pragma unroll
             for (int r = 0; r < 6; r++) {
                 const int slot = (headNow + 5 - r) % 6;        // r = 5: oldest output row (completes first)
-                const v2f tap = splat(st.td[kp + r * D]);
-                st.acc[slot][0] = fma2(r0, tap, st.acc[slot][0]);
-                st.acc[slot][1] = fma2(r1, tap, st.acc[slot][1]);
+                const int k = kp + r * D;
+                if (k == 0) {                                  // first contribution to a new output row: no zeroing needed
+                    st.acc[slot][0] = mul_tap<0>(r0, st.tdP[0]);
+                    st.acc[slot][1] = mul_tap<0>(r1, st.tdP[0]);
+                } else if (k & 1) {
+                    st.acc[slot][0] = fma_tap<1>(r0, st.tdP[k / 2], st.acc[slot][0]);
+                    st.acc[slot][1] = fma_tap<1>(r1, st.tdP[k / 2], st.acc[slot][1]);
+                } else {
+                    st.acc[slot][0] = fma_tap<0>(r0, st.tdP[k / 2], st.acc[slot][0]);
+                    st.acc[slot][1] = fma_tap<0>(r1, st.tdP[k / 2], st.acc[slot][1]);
+                }
             }
             if (kp == D - 1) {
                 // output row complete: H-down through LDS and store
                 const int uy = U * (i - 5) - (U - 1) + j + p.py0;
                 const int oy = (uy - (Cfg::FD - 1)) / D;       // exact
-                const v2f o0 = st.acc[headNow][0], o1 = st.acc[headNow][1];
-                st.acc[headNow][0] = splat(0.f); st.acc[headNow][1] = splat(0.f);
                 if (oy >= oy0 && oy < oy1) {                   // wave-uniform
-                    float* dst = sOut + (4 - delta) + 4 * lane;
+                    const v2f o0 = st.acc[headNow][0], o1 = st.acc[headNow][1];
+                    lds_f* dst = sOut + (4 - delta) + 4 * lane;
                     dst[0] = o0.x; dst[1] = o0.y; dst[2] = o1.x; dst[3] = o1.y;
                     wave_lds_sync();
+                    // lane l -> output columns 2l, 2l+1: upsampled samples 4l .. 4l+13 (+4 pad), four aligned b128 reads
+                    const lds_v4f* src = reinterpret_cast<const lds_v4f*>(sOut + 4 + 4 * lane);
+                    v2f pr[8];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { const v4f t = src[q]; pr[2 * q] = (v2f){t.x, t.y}; pr[2 * q + 1] = (v2f){t.z, t.w}; }
+                    v2f y0 = pr[0] * st.tdP[0], y1 = pr[1] * st.tdP[0];
+#pragma unroll
+                    for (int q = 1; q < Cfg::FD / 2; q++) { y0 = fma2(pr[q], st.tdP[q], y0); y1 = fma2(pr[q + 1], st.tdP[q], y1); }
+                    const float f0 = (y0.x + y0.y) * gain, f1 = (y1.x + y1.y) * gain;
                     T* orow = oplane + (long long)oy * p.ysH + ox0;
-#pragma unroll
-                    for (int o = 0; o < Cfg::OPL; o++) {
-                        const v2f* src = reinterpret_cast<const v2f*>(sOut + 4 + D * (lane + 64 * o));
-                        v2f s = splat(0.f);
-#pragma unroll
-                        for (int q = 0; q < Cfg::FD / 2; q++) s = fma2(src[q], (v2f){st.td[2 * q], st.td[2 * q + 1]}, s);
-                        const int col = lane + 64 * o;
-                        if (col < oxN) io<T>::st(orow + col, s.x + s.y);
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)orow, (short)0, oxN * (int)sizeof(T), 0x00020000);
+                    if (pairStore) {
+                        bufio<T>::st2(rs, 2 * lane * (int)sizeof(T), f0, f1);
+                    } else {
+                        bufio<T>::st1(rs, 2 * lane * (int)sizeof(T), f0);
+                        bufio<T>::st1(rs, (2 * lane + 1) * (int)sizeof(T), f1);
                     }
                     wave_lds_sync();
                 }
@@ -206,8 +279,8 @@ struct Stream {
     static __device__ __forceinline__ void run(const StreamParams& p) {
         static_assert(U % D == 0 && D == 2, "streaming kernel: down must be 2 and divide up");
         __shared__ __attribute__((aligned(16))) float lds[Cfg::SIN + Cfg::SOUT];
-        float* sIn = lds;
-        float* sOut = lds + Cfg::SIN;
+        lds_f* sIn = (lds_f*)lds;
+        lds_f* sOut = (lds_f*)lds + Cfg::SIN;
         const int lane = threadIdx.x;
 
         // XCD-aware renumbering: consecutive logical blocks (adjacent strips / chunks of one plane) share an XCD's L2
@@ -229,24 +302,35 @@ struct Stream {
         const T* plane = (const T*)p.x + (long long)n * p.xsN + (long long)c * p.xsC;
         T* oplane = (T*)p.y + (long long)n * p.ysN + (long long)c * p.ysC;
         const float bias = io<T>::ld((const T*)p.b + (long long)c * p.bStride);
+        // a pair store must not straddle the end of the row (and fp16 pairs must be dword aligned)
+        const bool pairStore = ((oxN & 1) == 0) &&
+            (sizeof(T) == 4 || (((((unsigned long long)oplane >> 1) + (unsigned long long)ox0) & 1) == 0 && (p.ysH & 1) == 0));
 
         State st;
-        // taps -> scalar registers; effective correlation taps g[k] = f[flip ? k : taps-1-k]
-        const float gU = (float)U, gV = (float)U * p.gain;
+        // taps -> scalar register pairs; effective correlation taps g[k] = f[flip ? k : taps-1-k]
+        const float gU = (float)U;
 #pragma unroll
-        for (int k = 0; k < Cfg::FU; k++) {
-            const float f = p.fu[p.flip ? k : Cfg::FU - 1 - k];
-            st.tu[k] = to_sgpr(f * gU);
-            st.tv[k] = to_sgpr(f * gV);
+        for (int m = 0; m < Cfg::FU / 2; m++) {
+            const float f1 = p.fu[p.flip ? 2 * m + 1 : Cfg::FU - 2 - 2 * m], f0 = p.fu[p.flip ? 2 * m : Cfg::FU - 1 - 2 * m];
+            st.tuP[m] = (v2f){to_sgpr(f1 * gU), to_sgpr(f0 * gU)};
         }
 #pragma unroll
-        for (int k = 0; k < Cfg::FD; k++) st.td[k] = to_sgpr(p.fd[p.flip ? k : Cfg::FD - 1 - k]);
+        for (int m = 0; m < Cfg::FD / 2; m++) {
+            const float f0 = p.fd[p.flip ? 2 * m : Cfg::FD - 1 - 2 * m], f1 = p.fd[p.flip ? 2 * m + 1 : Cfg::FD - 2 - 2 * m];
+            st.tdP[m] = (v2f){to_sgpr(f0), to_sgpr(f1)};
+        }
 
         // horizontal geometry: first upsampled column of the strip, shifted left by delta so that every lane's
         // U-column groups start at an upsampled position == 1 (mod U) and share one input window
         const int delta = ((D * ox0 - p.px0 - 1) % U + U) % U;
         const int uxs = D * ox0 - delta;
         const int ibase = floor_div(uxs - p.px0 - 1, U) + 1;
+#pragma unroll
+        for (int q = 0; q < Cfg::NL; q++) {
+            const int ix = ibase + lane + 64 * q;
+            st.coff[q] = ix * (int)sizeof(T);                  // negative / beyond the row -> out of range -> reads 0
+            st.bcol[q] = ((unsigned)ix < (unsigned)p.xW) ? bias : 0.f;
+        }
 
         // vertical geometry
         const int uyA = oy0 * D;
@@ -259,18 +343,18 @@ struct Stream {
         for (int s = 0; s < 6; s++) {
             st.w[s][0] = splat(0.f); st.w[s][1] = splat(0.f);
             st.acc[s][0] = splat(0.f); st.acc[s][1] = splat(0.f);
-            prefetch(st, s, p, plane, iFirst + s, ibase, lane, bias);
+            prefetch(st, s, p, plane, iFirst + s);
         }
 
         constexpr int ADV = U / D;                               // output rows completed per input row
         int i = iFirst;
         for (int blk = 0; blk < nBlocks; blk++, i += 6) {
-            step<0, (0 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 0, ibase, delta, lane, bias, oy0, oy1, ox0, oxN);
-            step<1, (1 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 1, ibase, delta, lane, bias, oy0, oy1, ox0, oxN);
-            step<2, (2 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 2, ibase, delta, lane, bias, oy0, oy1, ox0, oxN);
-            step<3, (3 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 3, ibase, delta, lane, bias, oy0, oy1, ox0, oxN);
-            step<4, (4 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 4, ibase, delta, lane, bias, oy0, oy1, ox0, oxN);
-            step<5, (5 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 5, ibase, delta, lane, bias, oy0, oy1, ox0, oxN);
+            step<0, (0 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 0, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<1, (1 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 1, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<2, (2 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 2, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<3, (3 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 3, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<4, (4 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 4, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<5, (5 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 5, delta, lane, oy0, oy1, ox0, oxN, pairStore);
         }
     }
 };
