@@ -217,9 +217,18 @@ SG3_API int sg3_bias_act(const sg3_bias_act_params* p, void* stream);
  * outH = H + 2*pad - k + 1.  k is 1 or 3.
  * ---------------------------------------------------------------------- */
 
-/* number of floats of the packed weight buffer for an [O,I,k,k] weight
- * (layout [O][ceil(I/KC)][k*k][KC], zero padded; KC depends on k). */
-SG3_API int64_t sg3_modconv_packed_floats(int O, int I, int k);
+/* arithmetic of the implicit GEMM */
+enum {
+    SG3_CONV_FP32  = 0,  /* v_mfma_f32_32x32x2_f32: exact fp32 products */
+    SG3_CONV_F16X3 = 1,  /* operands split x = hi + lo into two fp16 halves; hi*hi + hi*lo + lo*hi on
+                          * v_mfma_f32_32x32x16_f16 with fp32 accumulation: every retained product is exact, the
+                          * dropped lo*lo term is 2^-22 relative (fp32-equivalent), 5.3x the fp32 MFMA rate.
+                          * 3x3 kernels only; needs a bound on |x| (xBound) to keep the halves in fp16 range */
+};
+
+/* number of floats (4-byte units) of the packed weight buffer for an [O,I,k,k] weight
+ * (fp32: [O][ceil(I/KC)][k*k][KC] floats; f16x3: [O][ceil(I/16)][k*k][hi|lo][16] halfs; zero padded). */
+SG3_API int64_t sg3_modconv_packed_floats(int O, int I, int k, int precision);
 
 /* Demodulation coefficients and input scales
  * (models/stylegan3/networks_stylegan3.py:39-56):
@@ -243,6 +252,10 @@ typedef struct sg3_modconv_prep_params {
     int32_t        inputGainMode;
     int32_t        N, I, O, k;
     int32_t        demodulate;
+    int32_t        precision;  /* SG3_CONV_FP32 | SG3_CONV_F16X3 */
+    float          xBound;     /* f16x3 only: max |x| the conv will see (> 0).  sIn is scaled by a power of two per
+                                * sample so that |x * sIn| stays below 2^15, and dcoef (required, also without
+                                * demodulation) carries the inverse */
 } sg3_modconv_prep_params;
 
 SG3_API int sg3_modulated_conv2d_prep(const sg3_modconv_prep_params* p, void* stream);
@@ -257,6 +270,7 @@ typedef struct sg3_modconv_params {
     int32_t        N, I, O, H, W;
     int32_t        k;          /* 1 or 3 */
     int32_t        pad;
+    int32_t        precision;  /* must match the prep call that produced wPacked */
 } sg3_modconv_params;
 
 SG3_API int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream);

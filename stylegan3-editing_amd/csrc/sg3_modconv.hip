@@ -186,6 +186,204 @@ modconv_mfma_kernel(ConvParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// Split-precision variant (SG3_CONV_F16X3), 3x3 kernels.
+//
+// Every fp32 operand is split on the way into LDS into two fp16 halves, x = hi + lo with hi = fp16(x) and
+// lo = fp16(x - hi), and each 16-deep K step runs three v_mfma_f32_32x32x16_f16:  Ah*Bh + Ah*Bl + Al*Bh.
+// Products of two 11-bit significands are exact in the fp32 accumulator, so the only omission is lo*lo ~ 2^-22 of the
+// product -- the same order as fp32's own rounding -- at 16/3 = 5.3x the rate of the fp32 MFMA.  The prep kernel has
+// already split and packed the weights ([O][I/16][tap][hi|lo][16] halfs) and scaled sIn by a power of two per sample
+// so |x*sIn| < 2^15 given the caller's bound on |x| (dcoef carries the inverse power).
+// LDS image: A rows of 9 taps x (16 hi | 16 lo) halfs + 8 halfs of padding (conflict-free b128 rows); B as four
+// planes [channel-half][hi|lo][py][px][8 halfs], so a lane's im2col fragment for tap (ky,kx) is one ds_read_b128.
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct bufld;
+template <> struct bufld<float> {
+    static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+    }
+};
+template <> struct bufld<_Float16> {
+    static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, (int)off, 0, 0));
+    }
+};
+
+// x = hi + lo with hi = the top 11 significand bits of x (exactly representable in fp16 for normal-range values) and
+// lo = fp16(x - hi); two values per call, packed for the MFMA operand registers
+__device__ __forceinline__ void split2(float x0, float x1, v2h& hi, v2h& lo) {
+    const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x0) & 0xffffe000u);
+    const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x1) & 0xffffe000u);
+    hi = __builtin_bit_cast(v2h, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+    lo = __builtin_bit_cast(v2h, __builtin_amdgcn_cvt_pkrtz(x0 - h0, x1 - h1));
+}
+
+template <typename T, int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(256)
+modconv_f16x3_kernel(ConvParams p) {
+    constexpr int KS = 3, TAPS = 9, KC = 16;
+    constexpr int BM = WM * TM * 32;
+    constexpr int ROWS = WN * TN;
+    constexpr int PH = ROWS + KS - 1, PW = 32 + KS - 1;
+    constexpr int NPIX = PH * PW;
+    constexpr int AS = TAPS * 32 + 8;                  // halfs per A row in LDS (592 B)
+    constexpr int AROW_V = TAPS * 32 / 8;              // 16-byte vectors per packed A row (36)
+    constexpr int TPR = (BM == 32) ? 8 : (BM == 64 ? 4 : 2);     // threads that share one A row
+    constexpr int A_PER = (AROW_V + TPR - 1) / TPR;    // vectors per thread (immediate offsets 16 * TPR apart)
+    constexpr int BPLANE = NPIX * 8;                   // halfs per (channel-half, part) plane
+    constexpr int PX_PER = (NPIX + 255) / 256;         // patch pixels per thread
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(BM * TPR <= 256, "A staging map");
+
+    extern __shared__ __attribute__((aligned(16))) _Float16 smh[];
+    _Float16* sA = smh;
+    _Float16* sB = smh + BM * AS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    int bid = blockIdx.x;
+    {
+        const int nb = p.totalBlocks, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int mt = bid % p.mTiles; bid /= p.mTiles;
+    const int xt = bid % p.xTiles; bid /= p.xTiles;
+    const int yt = bid % p.yTiles; const int n = bid / p.yTiles;
+    const int o0 = mt * BM, x0 = xt * 32, y0 = yt * ROWS;
+
+    // ---- staging maps, fixed for the whole K loop (all addressing is descriptor + 32-bit offsets) ----
+    const unsigned HWb = (unsigned)(p.H * p.W) * (unsigned)sizeof(T);            // bytes per channel plane
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const T*)p.x + (size_t)n * p.I * p.H * p.W), (short)0, (int)((unsigned)p.I * HWb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.wp, (short)0, (int)((unsigned)p.O * (unsigned)p.nch * (unsigned)(AROW_V * 16)), 0x00020000);
+    // A: thread -> (row, first vector); its vectors are TPR * 16 bytes apart
+    const int arow = tid / TPR, acol = tid % TPR;
+    const bool aOk = arow < BM;
+    const unsigned aG = (aOk && o0 + arow < p.O) ? ((unsigned)(o0 + arow) * (unsigned)p.nch * (AROW_V * 16) + acol * 16) : 0x80000000u;
+    _Float16* aL = sA + arow * AS + acol * 8;
+    // B: thread -> PX_PER patch pixels (out-of-image pixels get an out-of-range offset and read as zero)
+    unsigned bG[PX_PER];
+    int bL[PX_PER];
+#pragma unroll
+    for (int q = 0; q < PX_PER; q++) {
+        const int e = tid + 256 * q;
+        const int px = e % PW, py = e / PW;
+        const int gy = y0 - p.pad + py, gx = x0 - p.pad + px;
+        const bool ok = e < NPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        bG[q] = ok ? (unsigned)(gy * p.W + gx) * (unsigned)sizeof(T) : 0x80000000u;
+        bL[q] = e < NPIX ? e * 8 : -1;
+    }
+    const float* sInN = p.sIn + (size_t)n * p.I;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; a++)
+#pragma unroll
+        for (int b = 0; b < TN; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    u32x4 ra[A_PER];
+    float rb[PX_PER][2][8];
+
+    auto fetch = [&](int ch) {
+        const unsigned aoff = aG + (unsigned)ch * (AROW_V * 16);
+#pragma unroll
+        for (int q = 0; q < A_PER; q++) {
+            if (AROW_V % TPR == 0 || acol + q * TPR < AROW_V)
+                ra[q] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)(aoff + q * TPR * 16), 0, 0);
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int ci = ch * KC + hf * 8 + c;                        // wave-uniform
+                const unsigned coff = (unsigned)ci * HWb;
+                const float sc = ci < p.I ? sInN[ci] : 0.f;                  // scalar load
+#pragma unroll
+                for (int q = 0; q < PX_PER; q++) rb[q][hf][c] = bufld<T>::ld(xr, bG[q] + coff) * sc;
+            }
+    };
+    auto stage = [&]() {
+        if (aOk) {
+#pragma unroll
+            for (int q = 0; q < A_PER; q++)
+                if (AROW_V % TPR == 0 || acol + q * TPR < AROW_V)
+                    *reinterpret_cast<u32x4*>(aL + q * TPR * 8) = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < PX_PER; q++) {
+            if (bL[q] < 0) continue;
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                v2h h[4], l[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) split2(rb[q][hf][2 * c], rb[q][hf][2 * c + 1], h[c], l[c]);
+                _Float16* dst = sB + (hf * 2) * BPLANE + bL[q];
+                *reinterpret_cast<v8h*>(dst) = __builtin_shufflevector(__builtin_shufflevector(h[0], h[1], 0, 1, 2, 3), __builtin_shufflevector(h[2], h[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
+                *reinterpret_cast<v8h*>(dst + BPLANE) = __builtin_shufflevector(__builtin_shufflevector(l[0], l[1], 0, 1, 2, 3), __builtin_shufflevector(l[2], l[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+    };
+
+    fetch(0);
+    for (int ch = 0; ch < p.nch; ch++) {
+        __syncthreads();
+        stage();
+        __syncthreads();
+        if (ch + 1 < p.nch) fetch(ch + 1);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; tap++) {
+            const int ky = tap / KS, kx = tap % KS;
+            v8h ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int a = 0; a < TM; a++) {
+                const _Float16* src = sA + ((wm * TM + a) * 32 + li) * AS + tap * 32 + lh * 8;
+                ah[a] = *reinterpret_cast<const v8h*>(src);
+                al[a] = *reinterpret_cast<const v8h*>(src + 16);
+            }
+#pragma unroll
+            for (int b = 0; b < TN; b++) {
+                const _Float16* src = sB + (lh * 2) * BPLANE + ((wn * TN + b + ky) * PW + li + kx) * 8;
+                bh[b] = *reinterpret_cast<const v8h*>(src);
+                bl[b] = *reinterpret_cast<const v8h*>(src + BPLANE);
+            }
+#pragma unroll
+            for (int a = 0; a < TM; a++)
+#pragma unroll
+                for (int b = 0; b < TN; b++) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                }
+        }
+    }
+
+    T* outp = (T*)p.out + (size_t)n * p.O * p.outH * p.outW;
+    const int gx = x0 + li;
+#pragma unroll
+    for (int a = 0; a < TM; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int o = o0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (o >= p.O) continue;
+            const float d = p.dcoef[(size_t)n * p.O + o];
+#pragma unroll
+            for (int b = 0; b < TN; b++) {
+                const int gy = y0 + wn * TN + b;
+                if (gy < p.outH && gx < p.outW)
+                    io<T>::st(outp + ((size_t)o * p.outH + gy) * p.outW + gx, acc[a][b][r] * d);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------
 // prep A: one workgroup per output channel: normalise the filter, pack it, and emit wsq[o][i] = sum_taps wn^2
 __global__ void __launch_bounds__(256)
 modconv_prep_w_kernel(sg3_modconv_prep_params p, int kc, int nch) {
@@ -201,11 +399,25 @@ modconv_prep_w_kernel(sg3_modconv_prep_params p, int kc, int nch) {
         for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
         scale = rsqrtf(red[0] / (float)len);
     }
-    float* dst = p.wPacked + (size_t)o * nch * taps * kc;
-    for (int j = threadIdx.x; j < nch * taps * kc; j += 256) {
-        const int c = j % kc, t = (j / kc) % taps, ch = j / (kc * taps);
-        const int i = ch * kc + c;
-        dst[j] = i < p.I ? w[i * taps + t] * scale : 0.f;
+    if (p.precision == SG3_CONV_F16X3) {
+        // [o][chunk][tap][hi|lo][16] halfs
+        _Float16* dsth = reinterpret_cast<_Float16*>(p.wPacked) + (size_t)o * nch * taps * 32;
+        for (int j = threadIdx.x; j < nch * taps * 16; j += 256) {
+            const int c = j % 16, t = (j / 16) % taps, ch = j / (16 * taps);
+            const int i = ch * 16 + c;
+            const float v = i < p.I ? w[i * taps + t] * scale : 0.f;
+            const _Float16 h = (_Float16)v;
+            _Float16* d = dsth + ((size_t)ch * taps + t) * 32 + c;
+            d[0] = h;
+            d[16] = (_Float16)(v - (float)h);
+        }
+    } else {
+        float* dst = p.wPacked + (size_t)o * nch * taps * kc;
+        for (int j = threadIdx.x; j < nch * taps * kc; j += 256) {
+            const int c = j % kc, t = (j / kc) % taps, ch = j / (kc * taps);
+            const int i = ch * kc + c;
+            dst[j] = i < p.I ? w[i * taps + t] * scale : 0.f;
+        }
     }
     for (int i = threadIdx.x; i < p.I; i += 256) {
         float s = 0.f;
@@ -218,7 +430,7 @@ modconv_prep_w_kernel(sg3_modconv_prep_params p, int kc, int nch) {
 __global__ void __launch_bounds__(256)
 modconv_prep_s_kernel(sg3_modconv_prep_params p) {
     __shared__ float red[256];
-    extern __shared__ float s2[];                         // [I] squared normalised styles of this sample
+    extern __shared__ float s2[];                         // [I] squared normalised styles | [I] scaled styles of this sample
     const int n = blockIdx.x;
     float scale = 1.f;
     if (p.demodulate) {
@@ -229,23 +441,41 @@ modconv_prep_s_kernel(sg3_modconv_prep_params p) {
         for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
         scale = rsqrtf(red[0] / (float)(p.N * p.I));
     }
+    float smax = 0.f;
     for (int i = threadIdx.x; i < p.I; i += 256) {
         const float sn = p.s[(size_t)n * p.I + i] * scale;
         float g = 1.f;
         if (p.inputGainMode == 1) g = p.inputGain[0];
         else if (p.inputGainMode == 2) g = p.inputGain[i];
         else if (p.inputGainMode == 3) g = p.inputGain[(size_t)n * p.I + i];
-        p.sIn[(size_t)n * p.I + i] = sn * g;
+        const float v = sn * g;
         s2[i] = sn * sn;
+        s2[p.I + i] = v;
+        smax = fmaxf(smax, fabsf(v));
+    }
+    // f16x3: per-sample power-of-two scale keeping |x * sIn| below 2^15
+    float down = 1.f, up = 1.f;
+    if (p.precision == SG3_CONV_F16X3) {
+        __syncthreads();
+        red[threadIdx.x] = smax;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]); __syncthreads(); }
+        const float peak = red[0] * p.xBound;
+        int e = 0;
+        if (peak > 32768.f) e = (int)ceilf(log2f(peak / 32768.f));
+        down = ldexpf(1.f, -e); up = ldexpf(1.f, e);
     }
     __syncthreads();
+    for (int i = threadIdx.x; i < p.I; i += 256) p.sIn[(size_t)n * p.I + i] = s2[p.I + i] * down;
     if (p.demodulate) {
         for (int o = threadIdx.x; o < p.O; o += 256) {
             const float* wq = p.wsq + (size_t)o * p.I;
             float s = 0.f;
             for (int i = 0; i < p.I; i++) s += wq[i] * s2[i];
-            p.dcoef[(size_t)n * p.O + o] = rsqrtf(s + 1e-8f);
+            p.dcoef[(size_t)n * p.O + o] = rsqrtf(s + 1e-8f) * up;
         }
+    } else if (p.precision == SG3_CONV_F16X3) {
+        for (int o = threadIdx.x; o < p.O; o += 256) p.dcoef[(size_t)n * p.O + o] = up;
     }
 }
 
@@ -285,12 +515,48 @@ static int dispatch_conv(const sg3_modconv_params& q, hipStream_t st) {
     }
 }
 
+template <typename T, int WM, int WN, int TM, int TN>
+static int launch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, ROWS = WN * TN;
+    constexpr int PH = ROWS + 2, PW = 34;
+    constexpr size_t ldsBytes = ((size_t)BM * (9 * 32 + 8) + 4 * (size_t)PH * PW * 8) * sizeof(_Float16);
+    ConvParams p;
+    p.x = q.x; p.wp = q.wPacked; p.sIn = q.sIn; p.dcoef = q.dcoef; p.out = q.out;
+    p.N = q.N; p.I = q.I; p.O = q.O; p.H = q.H; p.W = q.W; p.pad = q.pad;
+    p.outH = q.H + 2 * q.pad - 2; p.outW = q.W + 2 * q.pad - 2;
+    p.nch = ceil_div(q.I, 16);
+    p.xTiles = ceil_div(p.outW, 32); p.yTiles = ceil_div(p.outH, ROWS); p.mTiles = ceil_div(q.O, BM);
+    const long long total = (long long)p.xTiles * p.yTiles * p.mTiles * q.N;
+    if (total > 0x7fffffffLL) { set_error("modulated_conv2d: grid too large"); return SG3_BAD_ARG; }
+    p.totalBlocks = (int)total;
+    auto kern = modconv_f16x3_kernel<T, WM, WN, TM, TN>;
+    if (ldsBytes > 64 * 1024)
+        SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), ldsBytes, st, p);
+    SG3_LAUNCH_CHECK("modconv_f16x3_kernel");
+    return SG3_OK;
+}
+
+template <typename T>
+static int dispatch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
+    const int O = q.O;
+    // two workgroups per CU (<= 80 KB LDS each) so one stages while the other runs its MFMAs
+    if (O <= 32) return launch_conv_f16x3<T, 1, 4, 1, 4>(q, st);                    //  32 x (16 rows x 32)
+    const int t64 = ceil_div(O, 64) * 64, t96 = ceil_div(O, 96) * 96;
+    if (t96 < t64) return launch_conv_f16x3<T, 1, 4, 3, 2>(q, st);                  //  96 x (8 rows x 32)
+    return launch_conv_f16x3<T, 1, 4, 2, 2>(q, st);                                 //  64 x (8 rows x 32)
+}
+
 } // namespace sg3
 
 extern "C" {
 
-int64_t sg3_modconv_packed_floats(int O, int I, int k) {
+int64_t sg3_modconv_packed_floats(int O, int I, int k, int precision) {
     if (O <= 0 || I <= 0 || (k != 1 && k != 3)) return 0;
+    if (precision == SG3_CONV_F16X3) {
+        if (k != 3) return 0;
+        return (int64_t)O * sg3::ceil_div(I, 16) * 9 * 16;          // 32 halfs = 16 floats per (chunk, tap)
+    }
     const int kc = sg3::packed_kc(k);
     return (int64_t)O * sg3::ceil_div(I, kc) * (k * k) * kc;
 }
@@ -303,12 +569,17 @@ int sg3_modulated_conv2d_prep(const sg3_modconv_prep_params* p, void* stream) {
     SG3_REQUIRE(!p->demodulate || p->dcoef, "modulated_conv2d_prep: dcoef missing");
     SG3_REQUIRE(p->inputGainMode >= 0 && p->inputGainMode <= 3, "modulated_conv2d_prep: bad inputGainMode");
     SG3_REQUIRE(p->inputGainMode == 0 || p->inputGain, "modulated_conv2d_prep: inputGain missing");
-    SG3_REQUIRE((size_t)p->I * sizeof(float) <= 48 * 1024, "modulated_conv2d_prep: too many input channels");
+    SG3_REQUIRE((size_t)p->I * 2 * sizeof(float) <= 48 * 1024, "modulated_conv2d_prep: too many input channels");
+    SG3_REQUIRE(p->precision == SG3_CONV_FP32 || p->precision == SG3_CONV_F16X3, "modulated_conv2d_prep: bad precision");
+    if (p->precision == SG3_CONV_F16X3) {
+        SG3_REQUIRE(p->k == 3, "modulated_conv2d_prep: f16x3 needs a 3x3 kernel");
+        SG3_REQUIRE(p->xBound > 0.f && p->dcoef, "modulated_conv2d_prep: f16x3 needs xBound > 0 and a dcoef buffer");
+    }
     hipStream_t st = (hipStream_t)stream;
-    const int kc = packed_kc(p->k), nch = ceil_div(p->I, kc);
+    const int kc = packed_kc(p->k), nch = ceil_div(p->I, p->precision == SG3_CONV_F16X3 ? 16 : kc);
     hipLaunchKernelGGL(modconv_prep_w_kernel, dim3(p->O), dim3(256), 0, st, *p, kc, nch);
     SG3_LAUNCH_CHECK("modconv_prep_w_kernel");
-    hipLaunchKernelGGL(modconv_prep_s_kernel, dim3(p->N), dim3(256), (size_t)p->I * sizeof(float), st, *p);
+    hipLaunchKernelGGL(modconv_prep_s_kernel, dim3(p->N), dim3(256), (size_t)p->I * 2 * sizeof(float), st, *p);
     SG3_LAUNCH_CHECK("modconv_prep_s_kernel");
     return SG3_OK;
 }
@@ -320,11 +591,16 @@ int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream) {
     SG3_REQUIRE(p->k == 1 || p->k == 3, "modulated_conv2d: kernel size must be 1 or 3");
     SG3_REQUIRE(p->pad >= 0 && p->pad <= p->k - 1, "modulated_conv2d: padding must be in [0, k-1]");
     SG3_REQUIRE(p->H + 2 * p->pad - p->k + 1 > 0 && p->W + 2 * p->pad - p->k + 1 > 0, "modulated_conv2d: empty output");
+    SG3_REQUIRE(p->dtype == SG3_F32 || p->dtype == SG3_F16, "modulated_conv2d: unsupported dtype");
     hipStream_t st = (hipStream_t)stream;
+    if (p->precision == SG3_CONV_F16X3) {
+        SG3_REQUIRE(p->k == 3 && p->dcoef, "modulated_conv2d: f16x3 needs a 3x3 kernel and dcoef");
+        SG3_REQUIRE((int64_t)p->I * p->H * p->W * 4 < (int64_t)1 << 31, "modulated_conv2d: f16x3 needs a sample below 2 GiB (32-bit offsets)");
+        return p->dtype == SG3_F32 ? dispatch_conv_f16x3<float>(*p, st) : dispatch_conv_f16x3<_Float16>(*p, st);
+    }
+    SG3_REQUIRE(p->precision == SG3_CONV_FP32, "modulated_conv2d: bad precision");
     if (p->dtype == SG3_F32) return p->k == 3 ? dispatch_conv<float, 3>(*p, st) : dispatch_conv<float, 1>(*p, st);
-    if (p->dtype == SG3_F16) return p->k == 3 ? dispatch_conv<_Float16, 3>(*p, st) : dispatch_conv<_Float16, 1>(*p, st);
-    set_error("modulated_conv2d: unsupported dtype %d", p->dtype);
-    return SG3_BAD_ARG;
+    return p->k == 3 ? dispatch_conv<_Float16, 3>(*p, st) : dispatch_conv<_Float16, 1>(*p, st);
 }
 
 } // extern "C"

@@ -32,12 +32,13 @@ from torch_utils.ops import modulated_conv as _modconv
 
 
 @misc.profiled_function
-def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None):
+def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, x_bound=None):
     """x [N,I,H,W], w [O,I,kh,kw], s [N,I], input_gain [] | [I] | [N,I]  ->  [N,O,H',W'].
 
     Equals a per-sample convolution with weights  w * s[n] (unit-normalised and demodulated when `demodulate`) times
-    `input_gain` (reference :24-63)."""
-    return _modconv.modulated_conv2d(x, w, s, demodulate=demodulate, padding=padding, input_gain=input_gain)
+    `input_gain` (reference :24-63).  `x_bound` is an extension: a guaranteed bound on |x| that lets the HIP kernel use
+    its split-precision matrix-core path (torch_utils/ops/modulated_conv.py)."""
+    return _modconv.modulated_conv2d(x, w, s, demodulate=demodulate, padding=padding, input_gain=input_gain, x_bound=x_bound)
 
 # ----------------------------------------------------------------------------
 
@@ -259,6 +260,18 @@ class SynthesisLayer(torch.nn.Module):
 
     design_lowpass_filter = staticmethod(design_lowpass_filter)
 
+    def output_bound(self):
+        """Upper bound on |output|: the clamp value times the L1 norm of the down filter (None when unclamped).
+        Computed once from the filter buffer and cached; SynthesisNetwork hands it to the next layer's convolution."""
+        if self.conv_clamp is None:
+            return None
+        f = self.down_filter
+        key = None if f is None else (f.data_ptr(), f._version)
+        if getattr(self, '_bound_key', 0) != key:
+            l1 = 1.0 if f is None else float(f.abs().sum()) ** (2 if f.ndim == 1 else 1)
+            self._bound_key, self._bound = key, float(self.conv_clamp) * max(l1, 1.0) * 1.01
+        return self._bound
+
     def styles_from_w(self, w):
         """Per-input-channel modulation for latent w (ToRGB styles carry the 1/sqrt(fan_in) weight gain)."""
         styles = self.affine(w)
@@ -281,7 +294,7 @@ class SynthesisLayer(torch.nn.Module):
 
         dtype = torch.float16 if (self.use_fp16 and not force_fp32 and x.device.type == 'cuda') else torch.float32
         x = modulated_conv2d(x=x.to(dtype), w=self.weight, s=styles, padding=self.conv_kernel - 1,
-                             demodulate=(not self.is_torgb), input_gain=input_gain)
+                             demodulate=(not self.is_torgb), input_gain=input_gain, x_bound=getattr(self, 'input_bound', None))
         x = filtered_lrelu.filtered_lrelu(
             x=x, fu=self.up_filter, fd=self.down_filter, b=self.bias.to(x.dtype), up=self.up_factor, down=self.down_factor,
             padding=self.padding, gain=(1 if self.is_torgb else np.sqrt(2)), slope=(1 if self.is_torgb else 0.2), clamp=self.conv_clamp)
@@ -369,9 +382,18 @@ class SynthesisNetwork(torch.nn.Module):
     def layers(self):
         return [getattr(self, n) for n in self.layer_names]
 
+    def _propagate_bounds(self):
+        """Each layer's input is the previous layer's clamped + low-pass filtered output, so |x| is bounded; the first
+        layer (Fourier features) gets no bound and runs the exact-fp32 convolution."""
+        prev = None
+        for layer in self.layers():
+            layer.input_bound = None if prev is None else prev.output_bound()
+            prev = layer
+
     def forward(self, ws, all_s=None, **layer_kwargs):
         """ws [N, num_ws, w_dim]  ->  image [N, img_channels, R, R] (fp32).
         With `all_s` (dict from W2S, possibly edited) the affine layers are bypassed: StyleSpace path."""
+        self._propagate_bounds()
         if all_s is None:
             misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
             per_layer = ws.to(torch.float32).unbind(dim=1)

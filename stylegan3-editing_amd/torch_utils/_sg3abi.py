@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_PKG_ROOT, 'lib', 'libsg3hip.so')
 
 SG3_OK, SG3_NO_KERNEL, SG3_BAD_ARG, SG3_HIP_ERROR = 0, -1, -2, -3
 SG3_F32, SG3_F16, SG3_F64 = 0, 1, 2
+SG3_CONV_FP32, SG3_CONV_F16X3 = 0, 1
 _DTYPE = {torch.float32: SG3_F32, torch.float16: SG3_F16, torch.float64: SG3_F64}
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
@@ -51,13 +52,13 @@ class BiasActParams(ctypes.Structure):
 
 class ModconvParams(ctypes.Structure):
     _fields_ = [('x', c_vp), ('wPacked', c_vp), ('sIn', c_vp), ('dcoef', c_vp), ('out', c_vp), ('dtype', c_i32),
-                ('N', c_i32), ('I', c_i32), ('O', c_i32), ('H', c_i32), ('W', c_i32), ('k', c_i32), ('pad', c_i32)]
+                ('N', c_i32), ('I', c_i32), ('O', c_i32), ('H', c_i32), ('W', c_i32), ('k', c_i32), ('pad', c_i32), ('precision', c_i32)]
 
 
 class ModconvPrepParams(ctypes.Structure):
     _fields_ = [('w', c_vp), ('s', c_vp), ('wPacked', c_vp), ('wsq', c_vp), ('sIn', c_vp), ('dcoef', c_vp),
                 ('inputGain', c_vp), ('inputGainMode', c_i32),
-                ('N', c_i32), ('I', c_i32), ('O', c_i32), ('k', c_i32), ('demodulate', c_i32)]
+                ('N', c_i32), ('I', c_i32), ('O', c_i32), ('k', c_i32), ('demodulate', c_i32), ('precision', c_i32), ('xBound', c_f32)]
 
 
 # every symbol include/sg3_ops.h declares: (name, restype, argtypes)
@@ -72,7 +73,7 @@ EXPORTS = [
     ('sg3_upfirdn2d', ctypes.c_int, [ctypes.POINTER(Upfirdn2dParams), c_vp]),
     ('sg3_upfirdn2d_shape', ctypes.c_int, [ctypes.c_int] * 12 + [ctypes.POINTER(ctypes.c_int)] * 2),
     ('sg3_bias_act', ctypes.c_int, [ctypes.POINTER(BiasActParams), c_vp]),
-    ('sg3_modconv_packed_floats', ctypes.c_int64, [ctypes.c_int] * 3),
+    ('sg3_modconv_packed_floats', ctypes.c_int64, [ctypes.c_int] * 4),
     ('sg3_modulated_conv2d', ctypes.c_int, [ctypes.POINTER(ModconvParams), c_vp]),
     ('sg3_modulated_conv2d_prep', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), c_vp]),
 ]

@@ -23,6 +23,13 @@ import torch
 from .. import _sg3abi as abi
 from .. import misc
 
+# Arithmetic of the implicit GEMM for 3x3 kernels when the caller supplies a bound on |x| (`x_bound`):
+#   'f16x3' : fp16 hi/lo operand split, three fp16 MFMAs per K step, fp32 accumulation (fp32-equivalent: every
+#             retained product is exact, the dropped lo*lo term is 2^-22 relative) at 5.3x the fp32 MFMA rate;
+#   'fp32'  : v_mfma_f32_32x32x2_f32, exact fp32 products.
+# Calls without a bound (and all 1x1 kernels) always use 'fp32'.
+precision = 'f16x3'
+
 
 def _composite(x, w, s, demodulate, padding, input_gain):
     """The reference formulation with plain torch ops (differentiable; also the CPU / impl='ref' path)."""
@@ -40,7 +47,7 @@ def _composite(x, w, s, demodulate, padding, input_gain):
     return y.reshape(n, -1, *y.shape[2:])
 
 
-def _launch(x, w, s, demodulate, padding, input_gain):
+def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None):
     n, ci, h, wd = (int(v) for v in x.shape)
     co, ci2, k, k2 = (int(v) for v in w.shape)
     if k != k2 or ci != ci2 or k not in (1, 3):
@@ -63,10 +70,12 @@ def _launch(x, w, s, demodulate, padding, input_gain):
         else:
             gmode, g = 3, g.expand(n, ci).contiguous()
         gptr = g
-    wn = torch.empty([int(lib.sg3_modconv_packed_floats(co, ci, k))], dtype=torch.float32, device=dev)
+    split = precision == 'f16x3' and k == 3 and x_bound is not None and x_bound > 0
+    prec = abi.SG3_CONV_F16X3 if split else abi.SG3_CONV_FP32
+    wn = torch.empty([int(lib.sg3_modconv_packed_floats(co, ci, k, prec))], dtype=torch.float32, device=dev)
     wsq = torch.empty([co, ci], dtype=torch.float32, device=dev)
     s_in = torch.empty([n, ci], dtype=torch.float32, device=dev)
-    dcoef = torch.empty([n, co], dtype=torch.float32, device=dev) if demodulate else None
+    dcoef = torch.empty([n, co], dtype=torch.float32, device=dev) if (demodulate or split) else None
     oh, ow = h + 2 * padding - k + 1, wd + 2 * padding - k + 1
     out = torch.empty([n, co, oh, ow], dtype=x.dtype, device=dev)
     stream = abi.stream_ptr(dev)
@@ -75,21 +84,23 @@ def _launch(x, w, s, demodulate, padding, input_gain):
         pp.w, pp.s, pp.wPacked, pp.wsq, pp.sIn, pp.dcoef = abi.ptr(w32), abi.ptr(s32), abi.ptr(wn), abi.ptr(wsq), abi.ptr(s_in), abi.ptr(dcoef)
         pp.inputGain, pp.inputGainMode = abi.ptr(gptr), gmode
         pp.N, pp.I, pp.O, pp.k, pp.demodulate = n, ci, co, k, int(bool(demodulate))
+        pp.precision, pp.xBound = prec, float(x_bound) if split else 0.0
         abi.check(lib.sg3_modulated_conv2d_prep(ctypes.byref(pp), stream), 'sg3_modulated_conv2d_prep')
         cp = abi.ModconvParams()
         cp.x, cp.wPacked, cp.sIn, cp.dcoef, cp.out = abi.ptr(x), abi.ptr(wn), abi.ptr(s_in), abi.ptr(dcoef), abi.ptr(out)
         cp.dtype = abi.dtype_code(x.dtype)
         cp.N, cp.I, cp.O, cp.H, cp.W, cp.k, cp.pad = n, ci, co, h, wd, k, int(padding)
+        cp.precision = prec
         abi.check(lib.sg3_modulated_conv2d(ctypes.byref(cp), stream), 'sg3_modulated_conv2d')
     return out
 
 
 class _ModulatedConv2dHip(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, s, input_gain, demodulate, padding):  # pylint: disable=arguments-differ
+    def forward(ctx, x, w, s, input_gain, demodulate, padding, x_bound):  # pylint: disable=arguments-differ
         ctx.save_for_backward(x, w, s, input_gain if input_gain is not None else torch.empty(0))
         ctx.cfg = (demodulate, padding, input_gain is not None)
-        return _launch(x, w, s, demodulate, padding, input_gain)
+        return _launch(x, w, s, demodulate, padding, input_gain, x_bound)
 
     @staticmethod
     def backward(ctx, dy):  # pylint: disable=arguments-differ
@@ -105,15 +116,16 @@ class _ModulatedConv2dHip(torch.autograd.Function):
                     ins.append(t); idx.append(j)
             y = _composite(xd, wd, sd, demodulate, padding, gd)
             grads = torch.autograd.grad(y, ins, dy, create_graph=torch.is_grad_enabled(), allow_unused=True) if ins else []
-        out = [None] * 6
+        out = [None] * 7
         for j, gr in zip(idx, grads):
             out[j] = gr
         return tuple(out)
 
 
 @misc.profiled_function
-def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, impl='cuda'):
-    """x [N,I,H,W], w [O,I,k,k], s [N,I]; input_gain [], [I] or [N,I].  Returns [N,O,H+2p-k+1,W+2p-k+1] in x.dtype."""
+def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, impl='cuda', x_bound=None):
+    """x [N,I,H,W], w [O,I,k,k], s [N,I]; input_gain [], [I] or [N,I].  Returns [N,O,H+2p-k+1,W+2p-k+1] in x.dtype.
+    `x_bound` (optional float): a guaranteed upper bound on |x|; enables the split-precision MFMA path (see `precision`)."""
     assert impl in ['ref', 'cuda']
     with misc.suppress_tracer_warnings():
         n = int(x.shape[0])
@@ -122,5 +134,5 @@ def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, impl=
     misc.assert_shape(x, [n, i, None, None])
     misc.assert_shape(s, [n, i])
     if impl == 'cuda' and x.device.type == 'cuda':
-        return _ModulatedConv2dHip.apply(x, w, s, input_gain, bool(demodulate), int(padding))
+        return _ModulatedConv2dHip.apply(x, w, s, input_gain, bool(demodulate), int(padding), x_bound)
     return _composite(x, w, s, demodulate, padding, input_gain)

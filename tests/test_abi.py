@@ -82,9 +82,11 @@ def test_shape_errors_and_kernel_table():
     assert lib.sg3_filtered_lrelu_has_kernel(1, 1, 1, 1, 1, 1) == 1        # ToRGB
     assert lib.sg3_filtered_lrelu_has_kernel(2, 2, 12, 0, 12, 12) == 0     # radial down filter -> generic composition
     assert lib.sg3_filtered_lrelu_has_kernel(2, 4, 12, 0, 24, 0) == 0      # backward shape -> generic composition
-    assert lib.sg3_modconv_packed_floats(512, 512, 3) == 512 * 64 * 9 * 8
-    assert lib.sg3_modconv_packed_floats(81, 128, 3) == 81 * 16 * 9 * 8
-    assert lib.sg3_modconv_packed_floats(3, 32, 1) == 3 * 2 * 16
+    assert lib.sg3_modconv_packed_floats(512, 512, 3, _sg3abi.SG3_CONV_FP32) == 512 * 64 * 9 * 8
+    assert lib.sg3_modconv_packed_floats(81, 128, 3, _sg3abi.SG3_CONV_FP32) == 81 * 16 * 9 * 8
+    assert lib.sg3_modconv_packed_floats(3, 32, 1, _sg3abi.SG3_CONV_FP32) == 3 * 2 * 16
+    assert lib.sg3_modconv_packed_floats(81, 128, 3, _sg3abi.SG3_CONV_F16X3) == 81 * 8 * 9 * 16     # hi|lo halfs
+    assert lib.sg3_modconv_packed_floats(3, 32, 1, _sg3abi.SG3_CONV_F16X3) == 0                     # 3x3 only
 
 
 def test_gpu_tensor_without_library_raises(monkeypatch, tmp_path):

@@ -224,6 +224,34 @@ def test_modulated_conv2d_sizes(n, ci, co, h, k):
     assert maxabs(y2.cpu().numpy(), ref2) <= 3e-5 * max(1.0, float(np.abs(ref2).max()))
 
 
+@pytest.mark.parametrize('n,ci,co,h', [(2, 323, 203, 22), (1, 128, 81, 40), (2, 51, 32, 70), (2, 512, 512, 12), (1, 203, 128, 37), (3, 81, 51, 50)])
+def test_modulated_conv2d_split_precision(n, ci, co, h):
+    """fp16 hi/lo split on the fp16 matrix cores (x_bound given) is fp32-equivalent: compared with the fp64 result of
+    the oracle, its error is of the same order as the exact-fp32 MFMA kernel's.  Also large styles (power-of-two
+    rescale path) and a bound violated by nothing."""
+    from oracle import oracle as O
+    from torch_utils.ops import modulated_conv as mc
+    x = np.clip(rand(71, n, ci, h, h + 3) * 40, -256, 256).astype(np.float32); w = rand(72, co, ci, 3, 3); s = rand(73, n, ci) + 1
+    ref = O.modulated_conv2d(x.astype(np.float64), w.astype(np.float64), s.astype(np.float64), True, 2, 0.8)
+    scale = max(1.0, float(np.abs(ref).max()))
+    errs = {}
+    for prec in ('f16x3', 'fp32'):
+        mc.precision = prec
+        try:
+            y = mc.modulated_conv2d(T(x), T(w), T(s), demodulate=True, padding=2, input_gain=torch.tensor(0.8, device=DEV), x_bound=256.0)
+        finally:
+            mc.precision = 'f16x3'
+        errs[prec] = maxabs(y.cpu().numpy(), ref) / scale
+    print('relative max errors vs fp64:', errs)
+    assert errs['fp32'] <= 5e-6 and errs['f16x3'] <= 5e-6, errs     # K up to 4608 fp32 accumulation
+    # styles of magnitude 1e3: |x * s| would overflow fp16 without the per-sample power-of-two rescale
+    s_big = (s * 1000).astype(np.float32)
+    y = mc.modulated_conv2d(T(x), T(w), T(s_big), demodulate=False, padding=2, input_gain=None, x_bound=256.0)
+    ref2 = O.modulated_conv2d(x.astype(np.float64), w.astype(np.float64), s_big.astype(np.float64), False, 2, None)
+    assert bool(torch.isfinite(y).all())
+    assert maxabs(y.cpu().numpy(), ref2) <= 2e-6 * float(np.abs(ref2).max())
+
+
 def test_modulated_conv2d_fp16_and_grad():
     from oracle import oracle as O
     from models.stylegan3.networks_stylegan3 import modulated_conv2d
