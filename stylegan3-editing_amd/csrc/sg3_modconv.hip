@@ -222,7 +222,7 @@ __device__ __forceinline__ void split2(float x0, float x1, v2h& hi, v2h& lo) {
 }
 
 template <typename T, int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (TM * TN <= 4) ? 2 : 1)      // two workgroups per CU whenever the accumulators allow
 modconv_f16x3_kernel(ConvParams p) {
     constexpr int KS = 3, TAPS = 9, KC = 16;
     constexpr int BM = WM * TM * 32;
@@ -384,6 +384,77 @@ modconv_f16x3_kernel(ConvParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// 1x1 kernels with very few output channels (the ToRGB layer: 32 -> 3): HBM-bound, no matrix cores.
+// out[n,o,p] = dcoef[n,o] * sum_i wn[o,i] * sIn[n,i] * x[n,i,p]; a thread owns 4 consecutive pixels (16-byte loads
+// per channel plane), the modulated weights sit in LDS.
+template <typename T, int OMAX>
+__global__ void __launch_bounds__(256)
+modconv_1x1_small_kernel(ConvParams p, int vec) {
+    extern __shared__ float sw[];                       // [I][OMAX]
+    const int n = blockIdx.y;
+    const int HW = p.H * p.W;
+    for (int j = threadIdx.x; j < p.I * OMAX; j += 256) {
+        const int i = j / OMAX, o = j % OMAX;
+        float v = 0.f;
+        if (o < p.O) v = p.wp[((size_t)o * p.nch + i / 16) * 16 + (i % 16)] * p.sIn[(size_t)n * p.I + i] * (p.dcoef ? p.dcoef[(size_t)n * p.O + o] : 1.f);
+        sw[j] = v;
+    }
+    __syncthreads();
+    const T* xin = (const T*)p.x + (size_t)n * p.I * HW;
+    T* outp = (T*)p.out + (size_t)n * p.O * HW;
+    const int gs = gridDim.x * 256;
+    if (vec) {
+        for (int q = blockIdx.x * 256 + threadIdx.x; q * 4 < HW; q += gs) {
+            float acc[OMAX][4];
+#pragma unroll
+            for (int o = 0; o < OMAX; o++) { acc[o][0] = acc[o][1] = acc[o][2] = acc[o][3] = 0.f; }
+#pragma unroll 4
+            for (int i = 0; i < p.I; i++) {
+                float xv[4];
+                if (sizeof(T) == 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(xin + (size_t)i * HW + q * 4); xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w; }
+                else { for (int e = 0; e < 4; e++) xv[e] = io<T>::ld(xin + (size_t)i * HW + q * 4 + e); }
+#pragma unroll
+                for (int o = 0; o < OMAX; o++) { const float w = sw[i * OMAX + o];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[o][e] = fmaf(w, xv[e], acc[o][e]); }
+            }
+            for (int o = 0; o < p.O && o < OMAX; o++) {
+                if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(outp + (size_t)o * HW + q * 4) = (f32x4){acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
+                else for (int e = 0; e < 4; e++) io<T>::st(outp + (size_t)o * HW + q * 4 + e, acc[o][e]);
+            }
+        }
+    } else {
+        for (int q = blockIdx.x * 256 + threadIdx.x; q < HW; q += gs) {
+            float acc[OMAX];
+#pragma unroll
+            for (int o = 0; o < OMAX; o++) acc[o] = 0.f;
+            for (int i = 0; i < p.I; i++) {
+                const float xv = io<T>::ld(xin + (size_t)i * HW + q);
+#pragma unroll
+                for (int o = 0; o < OMAX; o++) acc[o] = fmaf(sw[i * OMAX + o], xv, acc[o]);
+            }
+            for (int o = 0; o < p.O && o < OMAX; o++) io<T>::st(outp + (size_t)o * HW + q, acc[o]);
+        }
+    }
+}
+
+template <typename T>
+static int launch_conv_1x1_small(const sg3_modconv_params& q, hipStream_t st) {
+    ConvParams p;
+    p.x = q.x; p.wp = q.wPacked; p.sIn = q.sIn; p.dcoef = q.dcoef; p.out = q.out;
+    p.N = q.N; p.I = q.I; p.O = q.O; p.H = q.H; p.W = q.W; p.pad = 0; p.outH = q.H; p.outW = q.W;
+    p.nch = ceil_div(q.I, ConvK<1>::KC);
+    p.xTiles = p.yTiles = p.mTiles = 1; p.totalBlocks = 0;
+    const int HW = q.H * q.W;
+    const int vec = (HW % 4 == 0) && (((size_t)q.x | (size_t)q.out) % 16 == 0) ? 1 : 0;
+    int bx = ceil_div(vec ? HW / 4 : HW, 256);
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL((modconv_1x1_small_kernel<T, 4>), dim3(bx, q.N), dim3(256), (size_t)q.I * 4 * sizeof(float), st, p, vec);
+    SG3_LAUNCH_CHECK("modconv_1x1_small_kernel");
+    return SG3_OK;
+}
+
+// ---------------------------------------------------------------------------
 // prep A: one workgroup per output channel: normalise the filter, pack it, and emit wsq[o][i] = sum_taps wn^2
 __global__ void __launch_bounds__(256)
 modconv_prep_w_kernel(sg3_modconv_prep_params p, int kc, int nch) {
@@ -541,7 +612,7 @@ template <typename T>
 static int dispatch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     const int O = q.O;
     // two workgroups per CU (<= 80 KB LDS each) so one stages while the other runs its MFMAs
-    if (O <= 32) return launch_conv_f16x3<T, 1, 4, 1, 4>(q, st);                    //  32 x (16 rows x 32)
+    if (O <= 32) return launch_conv_f16x3<T, 1, 4, 1, 2>(q, st);                    //  32 x (8 rows x 32)
     const int t64 = ceil_div(O, 64) * 64, t96 = ceil_div(O, 96) * 96;
     if (t96 < t64) return launch_conv_f16x3<T, 1, 4, 3, 2>(q, st);                  //  96 x (8 rows x 32)
     return launch_conv_f16x3<T, 1, 4, 2, 2>(q, st);                                 //  64 x (8 rows x 32)
@@ -599,6 +670,8 @@ int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream) {
         return p->dtype == SG3_F32 ? dispatch_conv_f16x3<float>(*p, st) : dispatch_conv_f16x3<_Float16>(*p, st);
     }
     SG3_REQUIRE(p->precision == SG3_CONV_FP32, "modulated_conv2d: bad precision");
+    if (p->k == 1 && p->pad == 0 && p->O <= 4 && (size_t)p->I * 4 * sizeof(float) <= 48 * 1024)
+        return p->dtype == SG3_F32 ? launch_conv_1x1_small<float>(*p, st) : launch_conv_1x1_small<_Float16>(*p, st);
     if (p->dtype == SG3_F32) return p->k == 3 ? dispatch_conv<float, 3>(*p, st) : dispatch_conv<float, 1>(*p, st);
     return p->k == 3 ? dispatch_conv<_Float16, 3>(*p, st) : dispatch_conv<_Float16, 1>(*p, st);
 }

@@ -143,6 +143,14 @@ class SynthesisInput(torch.nn.Module):
         self.register_buffer('freqs', freqs)
         self.register_buffer('phases', phases)
 
+    def output_bound(self):
+        """|features| <= max_o sum_c |weight[o,c]| / sqrt(C)  (|sin| <= 1, amplitudes <= 1); cached per weight version."""
+        key = (self.weight.data_ptr(), self.weight._version)
+        if getattr(self, '_bound_key', None) != key:
+            self._bound_key = key
+            self._bound = float(self.weight.detach().abs().sum(dim=1).max()) / float(np.sqrt(self.channels)) * 1.01
+        return self._bound
+
     def transform_params(self, w):
         """(r_c, r_s, t_x, t_y) predicted from w, rotation part normalised to unit length."""
         t = self.affine(w)
@@ -383,11 +391,11 @@ class SynthesisNetwork(torch.nn.Module):
         return [getattr(self, n) for n in self.layer_names]
 
     def _propagate_bounds(self):
-        """Each layer's input is the previous layer's clamped + low-pass filtered output, so |x| is bounded; the first
-        layer (Fourier features) gets no bound and runs the exact-fp32 convolution."""
-        prev = None
+        """Each layer's input is the previous layer's clamped + low-pass filtered output (or, for the first layer, the
+        Fourier features times a known matrix), so |x| has a cheap guaranteed bound."""
+        prev = self.input
         for layer in self.layers():
-            layer.input_bound = None if prev is None else prev.output_bound()
+            layer.input_bound = prev.output_bound()
             prev = layer
 
     def forward(self, ws, all_s=None, **layer_kwargs):
