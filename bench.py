@@ -120,6 +120,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
     ap.add_argument('--config', default='T1024')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a captured hipGraph')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -147,15 +148,27 @@ def main():
             return G.synthesis(ws, noise_mode='const', force_fp32=True)
 
     launches0 = _sg3abi.launch_count
+    graphed = None
+    if not args.eager:
+        # the timed job replays ONE captured hipGraph per step; per-kernel HIP-event timing for the roofline line is
+        # taken from an eager pass after the timed region (events cannot be recorded inside a graph replay)
+        from sg3_runtime import GraphedSynthesis
+        graphed = GraphedSynthesis(G, args.batch)
+        eager_step = step
+
+        def step():  # noqa: F811
+            return graphed(ws)
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    assert _sg3abi.launch_count - launches0 >= args.warmup * 30 or args.warmup == 0, 'HIP kernels did not run'
+    # eager: 30+ ABI launches per forward; graph: the launches were recorded at capture (warm-up + capture passes)
+    assert _sg3abi.launch_count - launches0 >= 30, 'HIP kernels did not run'
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
+    timer.enabled = args.eager
     t0 = time.perf_counter()
     for _ in range(args.steps):
         img = step()
@@ -164,6 +177,15 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    ksteps = args.steps
+    if graphed is not None:
+        # same kernels, same inputs, launched eagerly so each launch can be bracketed by events on its stream
+        ksteps = max(3, min(args.steps, 10))
+        timer.enabled = True
+        for _ in range(ksteps):
+            eager_step()
+        torch.cuda.synchronize()
+        timer.enabled = False
     assert tuple(img.shape) == (args.batch, 3, G.img_resolution, G.img_resolution) and bool(torch.isfinite(img).all())
 
     t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -173,8 +195,8 @@ def main():
 
     if rank == 0:
         total_bytes, _ = flrelu_algorithmic_bytes(G, args.batch)
-        fl_ms = timer.total_ms('filtered_lrelu') / max(args.steps, 1)        # per step, all 15 launches
-        conv_ms = timer.total_ms('modulated_conv2d') / max(args.steps, 1)
+        fl_ms = timer.total_ms('filtered_lrelu') / max(ksteps, 1)        # per step, all 15 launches
+        conv_ms = timer.total_ms('modulated_conv2d') / max(ksteps, 1)
         achieved = total_bytes / (fl_ms * 1e-3) / 1e9 if fl_ms > 0 else 0.0
         conv_flop = 0
         for name in G.synthesis.layer_names:
@@ -186,7 +208,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'StyleGAN3-T FFHQ-1024 Generator.synthesis forward, batch {args.batch} per GPU, force_fp32 '
-                                   f'(BASELINE configs[1]); seeded random weights', 'per_gpu_batch': args.batch, 'sharding': 'images'},
+                                   f'(BASELINE configs[1]); seeded random weights', 'per_gpu_batch': args.batch, 'sharding': 'images',
+                       'launch': 'eager' if args.eager else 'hipGraph replay'},
             'roofline': {'bound': 'hbm', 'kernel': 'flrelu_stream_kernel (+pointwise ToRGB)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                          'algorithmic_bytes_per_step': total_bytes, 'kernel_ms_per_step': fl_ms},

@@ -173,9 +173,9 @@ class SynthesisInput(torch.nn.Module):
         # fade out frequencies that the transform pushed beyond the band limit
         amps = (1 - (freqs.norm(dim=2) - self.bandwidth) / (self.sampling_rate / 2 - self.bandwidth)).clamp(0, 1)
 
-        theta = torch.eye(2, 3, device=device)
-        theta[0, 0] = 0.5 * self.size[0] / self.sampling_rate
-        theta[1, 1] = 0.5 * self.size[1] / self.sampling_rate
+        theta = torch.eye(2, 3, device=device)        # scaled in place by scalar kernels: no host->device copy, so the
+        theta[0, 0].mul_(0.5 * self.size[0] / self.sampling_rate)   # forward can be captured into a HIP graph
+        theta[1, 1].mul_(0.5 * self.size[1] / self.sampling_rate)
         grid = torch.nn.functional.affine_grid(theta.unsqueeze(0), [1, 1, self.size[1], self.size[0]], align_corners=False)
 
         x = (grid.unsqueeze(3) @ freqs.permute(0, 2, 1).unsqueeze(1).unsqueeze(2)).squeeze(3)   # [N,H,W,C]
