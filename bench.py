@@ -198,6 +198,13 @@ def main():
         fl_ms = timer.total_ms('filtered_lrelu') / max(ksteps, 1)        # per step, all 15 launches
         conv_ms = timer.total_ms('modulated_conv2d') / max(ksteps, 1)
         achieved = total_bytes / (fl_ms * 1e-3) / 1e9 if fl_ms > 0 else 0.0
+        # HBM traffic of the same 15 launches from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes over this
+        # command, summarised by tools/sum_traffic.py); only valid for the default workload
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'flrelu_traffic.json')
+        if os.path.exists(tfile) and args.batch == 8 and args.config == 'T1024':
+            with open(tfile) as f:
+                traffic = json.load(f)['traffic_bytes_per_step']
         conv_flop = 0
         for name in G.synthesis.layer_names:
             layer = getattr(G.synthesis, name)
@@ -211,7 +218,7 @@ def main():
                                    f'(BASELINE configs[1]); seeded random weights', 'per_gpu_batch': args.batch, 'sharding': 'images',
                        'launch': 'eager' if args.eager else 'hipGraph replay'},
             'roofline': {'bound': 'hbm', 'kernel': 'flrelu_stream_kernel (+pointwise ToRGB)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_step': total_bytes, 'kernel_ms_per_step': fl_ms},
             'modconv': {'bound': 'mfma', 'tflops': conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                         'peak_fp32_mfma_tflops': 157.3, 'kernel_ms_per_step': conv_ms},

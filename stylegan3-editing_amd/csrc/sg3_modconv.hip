@@ -202,13 +202,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T> struct bufld;
 template <> struct bufld<float> {
-    static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+    static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, (int)soff, 0));
     }
 };
 template <> struct bufld<_Float16> {
-    static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off) {
-        return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, (int)off, 0, 0));
+    static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+        return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, (int)off, (int)soff, 0));
     }
 };
 
@@ -304,10 +304,12 @@ modconv_f16x3_kernel(ConvParams p) {
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 const int ci = ch * KC + hf * 8 + c;                        // wave-uniform
-                const unsigned coff = (unsigned)ci * HWb;
+                // channel offset rides in the scalar offset (not range checked: padded channels alias channel 0 and
+                // are multiplied by zero); the pixel offset is the range-checked vector offset
+                const unsigned coff = ci < p.I ? (unsigned)ci * HWb : 0u;
                 const float sc = ci < p.I ? sInN[ci] : 0.f;                  // scalar load
 #pragma unroll
-                for (int q = 0; q < PX_PER; q++) rb[q][hf][c] = bufld<T>::ld(xr, bG[q] + coff) * sc;
+                for (int q = 0; q < PX_PER; q++) rb[q][hf][c] = bufld<T>::ld(xr, bG[q], coff) * sc;
             }
     };
     auto stage = [&]() {
@@ -332,36 +334,54 @@ modconv_f16x3_kernel(ConvParams p) {
         }
     };
 
+    // fragment loads for one tap; two register sets so tap t+1 is in flight while tap t's MFMAs issue
+    struct Frags { v8h ah[TM], al[TM], bh[TN], bl[TN]; };
+    auto load_frags = [&](Frags& f, int tap) {
+        const int ky = tap / KS, kx = tap % KS;
+#pragma unroll
+        for (int a = 0; a < TM; a++) {
+            const _Float16* src = sA + ((wm * TM + a) * 32 + li) * AS + tap * 32 + lh * 8;
+            f.ah[a] = *reinterpret_cast<const v8h*>(src);
+            f.al[a] = *reinterpret_cast<const v8h*>(src + 16);
+        }
+#pragma unroll
+        for (int b = 0; b < TN; b++) {
+            const _Float16* src = sB + (lh * 2) * BPLANE + ((wn * TN + b + ky) * PW + li + kx) * 8;
+            f.bh[b] = *reinterpret_cast<const v8h*>(src);
+            f.bl[b] = *reinterpret_cast<const v8h*>(src + BPLANE);
+        }
+    };
+    auto mfma_tap = [&](const Frags& f) {
+#pragma unroll
+        for (int a = 0; a < TM; a++)
+#pragma unroll
+            for (int b = 0; b < TN; b++) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[a], f.bh[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bl[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bh[b], acc[a][b], 0, 0, 0);
+            }
+    };
+
     fetch(0);
     for (int ch = 0; ch < p.nch; ch++) {
         __syncthreads();
         stage();
         __syncthreads();
         if (ch + 1 < p.nch) fetch(ch + 1);
+        Frags f0, f1;
+        load_frags(f0, 0);
 #pragma unroll
-        for (int tap = 0; tap < TAPS; tap++) {
-            const int ky = tap / KS, kx = tap % KS;
-            v8h ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int a = 0; a < TM; a++) {
-                const _Float16* src = sA + ((wm * TM + a) * 32 + li) * AS + tap * 32 + lh * 8;
-                ah[a] = *reinterpret_cast<const v8h*>(src);
-                al[a] = *reinterpret_cast<const v8h*>(src + 16);
+        for (int tap = 0; tap < TAPS; tap += 2) {
+            if (tap + 1 < TAPS) load_frags(f1, tap + 1);
+            __builtin_amdgcn_sched_barrier(0);          // keep the next tap's ds_reads ahead of this tap's MFMAs
+            mfma_tap(f0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < TAPS) {
+                if (tap + 2 < TAPS) load_frags(f0, tap + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tap(f1);
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int b = 0; b < TN; b++) {
-                const _Float16* src = sB + (lh * 2) * BPLANE + ((wn * TN + b + ky) * PW + li + kx) * 8;
-                bh[b] = *reinterpret_cast<const v8h*>(src);
-                bl[b] = *reinterpret_cast<const v8h*>(src + BPLANE);
-            }
-#pragma unroll
-            for (int a = 0; a < TM; a++)
-#pragma unroll
-                for (int b = 0; b < TN; b++) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-                }
         }
     }
 

@@ -1,0 +1,70 @@
+"""Micro-benchmark of single synthesis-layer kernels at FFHQ-1024 config-T shapes (batch 8), for profiling.
+
+    python tools/bench_layer.py flrelu L10 [--iters 20]      # filtered_lrelu of layer L10
+    python tools/bench_layer.py conv L6                      # modulated conv of layer L6
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, 'stylegan3-editing_amd'), os.path.join(ROOT, 'tests'), ROOT):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('op', choices=['flrelu', 'conv'])
+    ap.add_argument('layers', nargs='+')
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--dtype', default='float32')
+    ap.add_argument('--precision', default='f16x3')
+    a = ap.parse_args()
+    from models.stylegan3.networks_stylegan3 import Generator
+    from synth_weights import CONFIGS
+    from torch_utils.ops import filtered_lrelu, modulated_conv
+    modulated_conv.precision = a.precision
+    dev = 'cuda:0'
+    G = Generator(**CONFIGS['T1024']).eval().requires_grad_(False)
+    dt = getattr(torch, a.dtype)
+    for lname in a.layers:
+        layer = [getattr(G.synthesis, n) for n in G.synthesis.layer_names if n.startswith(lname + '_')][0].to(dev)
+        k = layer.conv_kernel
+        ins = int(layer.in_size[0])
+        if a.op == 'flrelu':
+            x = torch.randn(a.batch, layer.out_channels, ins + k - 1, ins + k - 1, device=dev, dtype=dt)
+            b = torch.randn(layer.out_channels, device=dev, dtype=dt)
+
+            def run():
+                return filtered_lrelu.filtered_lrelu(x, fu=layer.up_filter, fd=layer.down_filter, b=b, up=layer.up_factor, down=layer.down_factor,
+                                                     padding=layer.padding, gain=np.sqrt(2), slope=0.2, clamp=256)
+            outs = int(layer.out_size[0])
+            work = a.batch * layer.out_channels * ((ins + k - 1) ** 2 + outs ** 2) * x.element_size()
+            unit, scale = 'TB/s', 1e-12
+        else:
+            x = (torch.randn(a.batch, layer.in_channels, ins, ins, device=dev) * 2).clamp(-256, 256).to(dt)
+            s = torch.randn(a.batch, layer.in_channels, device=dev) + 1
+            w = layer.weight
+
+            def run():
+                return modulated_conv.modulated_conv2d(x, w, s, demodulate=True, padding=k - 1, input_gain=torch.ones([], device=dev), x_bound=256.0)
+            work = 2 * a.batch * layer.in_channels * layer.out_channels * k * k * (ins + k - 1) ** 2
+            unit, scale = 'TFLOP/s', 1e-12
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        print(f'{a.op} {lname}: {ms * 1e3:9.1f} us  {work / (ms * 1e-3) * scale:8.2f} {unit}', flush=True)
+
+
+if __name__ == '__main__':
+    main()
