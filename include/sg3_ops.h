@@ -275,6 +275,40 @@ typedef struct sg3_modconv_params {
 
 SG3_API int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream);
 
+/* ------------------------------------------------------------------------
+ * conv2d -- the plain convolutions of the ReStyle encoder (IR-SE50 backbone and
+ *   GradualStyleBlock heads): replaces the torch.nn.Conv2d / BatchNorm2d / PReLU /
+ *   LeakyReLU module calls of models/setgan/encoder/encoders/helpers.py:98-120,
+ *   restyle_psp_encoders.py:26-28 and map2style.py:15-19 for eval-mode inference.
+ *
+ *   out[n,o,y,x] = act( bias[o] + sum_{i,ky,kx} w[o,i,ky,kx] *
+ *                       pre(x[n,i, y*stride+ky-pad, x*stride+kx-pad]) )
+ *   pre(v) = v * inScale[i] + inShift[i] inside the image, 0 in the padding
+ *            (an eval-mode BatchNorm in FRONT of the convolution, helpers.py:108);
+ *   a BatchNorm BEHIND the convolution is folded into w / bias by the caller.
+ *   act: 0 none, 1 PReLU with per-channel slope[o], 2 leaky ReLU with slope[0].
+ * Exact fp32 matrix-core arithmetic (v_mfma_f32_32x32x2_f32), NCHW contiguous
+ * fp32 tensors, k in {1,3}, stride in {1,2}.
+ * wPacked comes from sg3_conv2d_pack (layout [O][ceil(I/KC)][k*k][KC]).
+ * ---------------------------------------------------------------------- */
+typedef struct sg3_conv2d_params {
+    const float*   x;          /* [N,I,H,W] */
+    const float*   wPacked;    /* sg3_modconv_packed_floats(O,I,k,SG3_CONV_FP32) floats */
+    const float*   inScale;    /* [I] or NULL */
+    const float*   inShift;    /* [I] or NULL (NULL = 0) */
+    const float*   bias;       /* [O] or NULL */
+    const float*   slope;      /* act 1: [O]; act 2: [1]; else ignored */
+    float*         out;        /* [N,O,outH,outW] */
+    int32_t        N, I, O, H, W;
+    int32_t        k, stride, pad;
+    int32_t        act;
+} sg3_conv2d_params;
+
+SG3_API int sg3_conv2d(const sg3_conv2d_params* p, void* stream);
+
+/* w [O,I,k,k] (* outScale[o] when given: a folded BatchNorm) -> packed layout */
+SG3_API int sg3_conv2d_pack(const float* w, const float* outScale, float* wPacked, int O, int I, int k, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

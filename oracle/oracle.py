@@ -439,3 +439,60 @@ def filter_taps_for(sched):
         if fd is not None:
             out[p + 'down_filter'] = fd
     return out
+
+
+# ----------------------------------------------------------------------------
+# ReStyle encoder (eval mode)
+
+def _bn(x, sd, p, eps=1e-5):
+    a = sd[p + 'weight'] / np.sqrt(sd[p + 'running_var'] + eps)
+    b = sd[p + 'bias'] - sd[p + 'running_mean'] * a
+    return (x * a[None, :, None, None] + b[None, :, None, None]).astype(np.float32)
+
+
+def _prelu(x, slope):
+    return np.where(x >= 0, x, x * slope[None, :, None, None]).astype(np.float32)
+
+
+def bottleneck_ir_se(sd, p, x, stride):
+    """models/setgan/encoder/encoders/helpers.py:98-120 (eval): BN, conv3x3, PReLU, conv3x3(stride), BN, SE; + shortcut."""
+    r = _bn(x, sd, p + 'res_layer.0.')
+    r = conv2d(r, sd[p + 'res_layer.1.weight'], None, 1, 1)
+    r = _prelu(r, sd[p + 'res_layer.2.weight'])
+    r = conv2d(r, sd[p + 'res_layer.3.weight'], None, stride, 1)
+    r = _bn(r, sd, p + 'res_layer.4.')
+    pooled = r.mean(axis=(2, 3))                                                      # helpers.py:66
+    g = np.maximum(pooled @ sd[p + 'res_layer.5.fc1.weight'][:, :, 0, 0].T, 0)
+    g = 1.0 / (1.0 + np.exp(-(g @ sd[p + 'res_layer.5.fc2.weight'][:, :, 0, 0].T)))
+    r = r * g[:, :, None, None].astype(np.float32)
+    if p + 'shortcut_layer.0.weight' in sd:
+        s = conv2d(x, sd[p + 'shortcut_layer.0.weight'], None, stride, 0)
+        s = _bn(s, sd, p + 'shortcut_layer.1.')
+    else:
+        s = x[:, :, ::stride, ::stride]                                               # MaxPool2d(1, stride)
+    return (r + s).astype(np.float32)
+
+
+def backbone_encoder(sd, x, num_layers=50, n_styles=16, return_feats=False):
+    """models/setgan/encoder/encoders/restyle_psp_encoders.py:43-50 with helpers.get_blocks (:30-55), mode 'ir_se'."""
+    units = {50: (3, 4, 14, 3), 100: (3, 13, 30, 3), 152: (3, 8, 36, 3)}[num_layers]
+    h = conv2d(x, sd['input_layer.0.weight'], None, 1, 1)
+    h = _prelu(_bn(h, sd, 'input_layer.1.'), sd['input_layer.2.weight'])
+    feats = {'stem': h}
+    i = 0
+    for n_units in units:
+        for u in range(n_units):
+            h = bottleneck_ir_se(sd, f'body.{i}.', h, 2 if u == 0 else 1)
+            feats[f'body{i}'] = h
+            i += 1
+    codes = []
+    for j in range(n_styles):
+        t = h
+        for c in (0, 2, 4, 6):                                                        # map2style.py:15-19
+            t = conv2d(t, sd[f'styles.{j}.convs.{c}.weight'], sd[f'styles.{j}.convs.{c}.bias'], 2, 1)
+            t = np.where(t >= 0, t, t * np.float32(0.01)).astype(np.float32)          # nn.LeakyReLU() default slope
+        t = t.reshape(-1, t.shape[1])
+        w = sd[f'styles.{j}.linear.weight'] * np.float32(1.0 / np.sqrt(t.shape[1]))   # EqualLinear, lr_mul = 1
+        codes.append(t @ w.T + sd[f'styles.{j}.linear.bias'][None])
+    codes = np.stack(codes, axis=1).astype(np.float32)
+    return (codes, feats) if return_feats else codes

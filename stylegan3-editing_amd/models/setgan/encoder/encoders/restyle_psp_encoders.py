@@ -1,0 +1,94 @@
+"""ReStyle-pSp encoder backbones (reference models/setgan/encoder/encoders/restyle_psp_encoders.py).
+
+`BackboneEncoder` (:10-50): conv3x3(input_nc -> 64) + BN + PReLU at 256^2, the IR / IR-SE stages down to [N,512,16,16],
+then `n_styles` GradualStyleBlock heads, stacked to [N, n_styles, 512].  Module names and therefore state_dict keys are
+the reference's.  In eval mode on a GPU the forward runs on libsg3hip's matrix-core convolution with BatchNorm / PReLU
+/ leaky-ReLU fused, and the first convolution of all heads (same input) is executed as ONE convolution with
+n_styles*512 output channels.  `ResNetBackboneEncoder` (:53-97) needs torchvision's pretrained ResNet34, which is
+neither installed nor downloadable here; constructing it raises with that explanation.
+"""
+import torch
+from torch import nn
+from torch.nn import BatchNorm2d, Conv2d, Module, PReLU, Sequential
+
+from models.setgan.encoder.encoders.helpers import bottleneck_IR, bottleneck_IR_SE, get_blocks
+from models.setgan.encoder.encoders.map2style import GradualStyleBlock
+
+
+class BackboneEncoder(Module):
+    def __init__(self, num_layers, mode='ir', n_styles=18, opts=None):
+        super().__init__()
+        assert num_layers in [50, 100, 152], 'num_layers should be 50,100, or 152'
+        assert mode in ['ir', 'ir_se'], 'mode should be ir or ir_se'
+        unit = bottleneck_IR if mode == 'ir' else bottleneck_IR_SE
+        input_nc = getattr(opts, 'input_nc', 6) if opts is not None else 6
+        self.input_layer = Sequential(Conv2d(input_nc, 64, (3, 3), 1, 1, bias=False), BatchNorm2d(64), PReLU(64))
+        self.body = Sequential(*[unit(b.in_channel, b.depth, b.stride) for stage in get_blocks(num_layers) for b in stage])
+        self.styles = nn.ModuleList([GradualStyleBlock(512, 512, 16) for _ in range(n_styles)])
+        self.style_count = n_styles
+        self._packed = None
+
+    # plain PyTorch definition (CPU, training)
+    def _forward_torch(self, x):
+        x = self.body(self.input_layer(x))
+        return torch.stack([style(x) for style in self.styles], dim=1)
+
+    def invalidate_packed(self):
+        """Drop the packed / folded weights (call after changing parameters or BatchNorm statistics)."""
+        self._packed = None
+        for m in self.body:
+            m._packed = None
+
+    def train(self, mode=True):
+        self.invalidate_packed()
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.invalidate_packed()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_packed()          # .to(device) / .float() move the parameters the packed copies came from
+        return super()._apply(fn, *args, **kwargs)
+
+    def _pack(self):
+        from torch_utils.ops.plain_conv import ACT_LRELU, ACT_PRELU, PackedConv, bn_affine
+        conv, bn, prelu = self.input_layer[0], self.input_layer[1], self.input_layer[2]
+        a, b = bn_affine(bn)
+        pk = dict(stem=PackedConv(conv.weight, out_scale=a, bias=b, act=ACT_PRELU, slope=prelu.weight, stride=1, padding=1))
+        slope = torch.tensor([self.styles[0].convs[1].negative_slope], dtype=torch.float32, device=conv.weight.device)
+        # first head convolution of every style block reads the same feature map: one convolution, n_styles*512 outputs
+        w0 = torch.cat([s.convs[0].weight for s in self.styles], dim=0)
+        b0 = torch.cat([s.convs[0].bias for s in self.styles], dim=0)
+        pk['heads0'] = PackedConv(w0, bias=b0, act=ACT_LRELU, slope=slope, stride=2, padding=1)
+        pk['heads'] = [[PackedConv(s.convs[i].weight, bias=s.convs[i].bias, act=ACT_LRELU, slope=slope, stride=2, padding=1)
+                        for i in range(2, len(s.convs), 2)] for s in self.styles]
+        self._packed = pk
+
+    def _forward_hip(self, x):
+        if self._packed is None:
+            self._pack()
+        pk = self._packed
+        x = pk['stem'](x.float())
+        for unit in self.body:
+            x = unit.forward_hip(x)
+        h0 = pk['heads0'](x)                                   # [N, n_styles*512, 8, 8]
+        outs = []
+        for j, style in enumerate(self.styles):
+            h = h0[:, j * style.out_c:(j + 1) * style.out_c]
+            for conv in pk['heads'][j]:
+                h = conv(h)
+            outs.append(style.linear(h.reshape(-1, style.out_c)))
+        return torch.stack(outs, dim=1)
+
+    def forward(self, x):
+        if x.is_cuda and not self.training and not torch.is_grad_enabled():
+            return self._forward_hip(x)
+        return self._forward_torch(x)
+
+
+class ResNetBackboneEncoder(Module):
+    def __init__(self, n_styles=18, opts=None):
+        super().__init__()
+        raise RuntimeError('ResNetBackboneEncoder needs torchvision.models.resnet34(pretrained=True) (reference '
+                           'restyle_psp_encoders.py:65); torchvision and its weights are not available in this offline build')

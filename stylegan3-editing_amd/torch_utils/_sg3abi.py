@@ -61,6 +61,12 @@ class ModconvPrepParams(ctypes.Structure):
                 ('N', c_i32), ('I', c_i32), ('O', c_i32), ('k', c_i32), ('demodulate', c_i32), ('precision', c_i32), ('xBound', c_f32)]
 
 
+class Conv2dParams(ctypes.Structure):
+    _fields_ = [('x', c_vp), ('wPacked', c_vp), ('inScale', c_vp), ('inShift', c_vp), ('bias', c_vp), ('slope', c_vp), ('out', c_vp),
+                ('N', c_i32), ('I', c_i32), ('O', c_i32), ('H', c_i32), ('W', c_i32), ('k', c_i32), ('stride', c_i32), ('pad', c_i32),
+                ('act', c_i32)]
+
+
 # every symbol include/sg3_ops.h declares: (name, restype, argtypes)
 EXPORTS = [
     ('sg3_abi_version', ctypes.c_int, []),
@@ -76,6 +82,8 @@ EXPORTS = [
     ('sg3_modconv_packed_floats', ctypes.c_int64, [ctypes.c_int] * 4),
     ('sg3_modulated_conv2d', ctypes.c_int, [ctypes.POINTER(ModconvParams), c_vp]),
     ('sg3_modulated_conv2d_prep', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), c_vp]),
+    ('sg3_conv2d', ctypes.c_int, [ctypes.POINTER(Conv2dParams), c_vp]),
+    ('sg3_conv2d_pack', ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp]),
 ]
 
 _lib = None

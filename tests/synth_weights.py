@@ -100,3 +100,41 @@ def make_user_transform(translate=(0.1, -0.05), angle_deg=15.0):
     m[0][0] = c; m[0][1] = s; m[0][2] = translate[0]
     m[1][0] = -s; m[1][1] = c; m[1][2] = translate[1]
     return np.linalg.inv(m).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+# ReStyle encoder (IR-SE50 + 16 GradualStyleBlock heads): He-scaled weights and non-trivial BatchNorm statistics so
+# that activations stay O(1) through 50 layers and every fused term (BN in front / behind, PReLU, SE) is exercised.
+
+def synth_encoder_tensor(key, shape, seed=0):
+    r = _rs(seed + 17, key)
+    shape = tuple(int(s) for s in shape)
+    leaf = key.split('.')[-1]
+    if leaf == 'num_batches_tracked':
+        return np.asarray(100, dtype=np.int64)
+    if leaf == 'running_mean':
+        return (0.1 * r.randn(*shape)).astype(np.float32)
+    if leaf == 'running_var':
+        return r.uniform(0.5, 1.5, size=shape).astype(np.float32)
+    if len(shape) == 4:                                   # conv weight [O,I,k,k]
+        fan_in = shape[1] * shape[2] * shape[3]
+        return (r.randn(*shape) * np.sqrt(1.0 / fan_in)).astype(np.float32)
+    if len(shape) == 2:                                   # EqualLinear weight (scaled by 1/sqrt(in) in forward)
+        return r.randn(*shape).astype(np.float32)
+    if 'linear' in key and leaf == 'bias':
+        return (0.1 * r.randn(*shape)).astype(np.float32)
+    if 'convs' in key and leaf == 'bias':
+        return (0.05 * r.randn(*shape)).astype(np.float32)
+    # 1-D: BatchNorm weight / bias or PReLU slope; told apart by the module position in the reference layout
+    parts = key.split('.')
+    if leaf == 'weight' and (parts[-2] == '2' and parts[0] in ('input_layer',) or (len(parts) >= 3 and parts[-3] == 'res_layer' and parts[-2] == '2')):
+        return r.uniform(0.1, 0.4, size=shape).astype(np.float32)        # PReLU
+    if leaf == 'weight':
+        return r.uniform(0.7, 1.3, size=shape).astype(np.float32)        # BatchNorm gamma
+    if leaf == 'bias':
+        return (0.1 * r.randn(*shape)).astype(np.float32)                # BatchNorm beta
+    raise KeyError(key)
+
+
+def synth_encoder_state_dict(manifest, seed=0):
+    return {k: synth_encoder_tensor(k, manifest[k], seed=seed) for k in sorted(manifest)}

@@ -1,0 +1,67 @@
+"""GPU: the ReStyle encoder on libsg3hip's matrix-core convolution (BatchNorm / PReLU / leaky ReLU fused) against the
+golden vectors built from the reference's residual units, and the fused conv2d op against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, maxabs
+from test_encoder_cpu import _input, build_product_encoder
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.mark.parametrize('n,ci,co,h,w,k,stride,pad,act', [
+    (2, 6, 64, 40, 44, 3, 1, 1, 1), (1, 64, 64, 33, 31, 3, 2, 1, 0), (2, 64, 128, 20, 24, 1, 2, 0, 0), (1, 128, 256, 16, 16, 3, 1, 1, 1),
+    (2, 512, 512, 16, 16, 3, 2, 1, 2), (3, 512, 512, 2, 2, 3, 2, 1, 2), (1, 100, 70, 19, 23, 3, 1, 1, 2), (1, 48, 8192, 9, 9, 3, 2, 1, 2)])
+def test_conv2d_fused(n, ci, co, h, w, k, stride, pad, act):
+    from oracle import oracle as O
+    from torch_utils.ops.plain_conv import PackedConv
+    r = np.random.RandomState(5)
+    x = r.randn(n, ci, h, w).astype(np.float32); wt = (r.randn(co, ci, k, k) / np.sqrt(ci * k * k)).astype(np.float32)
+    a_in, b_in = r.uniform(0.5, 1.5, ci).astype(np.float32), (0.2 * r.randn(ci)).astype(np.float32)
+    a_out, bias = r.uniform(0.5, 1.5, co).astype(np.float32), (0.2 * r.randn(co)).astype(np.float32)
+    slope = r.uniform(0.1, 0.4, co).astype(np.float32) if act == 1 else np.asarray([0.01], np.float32)
+    T = lambda v: torch.from_numpy(v).to(DEV)  # noqa: E731
+    conv = PackedConv(T(wt), out_scale=T(a_out), bias=T(bias), in_scale=T(a_in), in_shift=T(b_in), act=act, slope=T(slope), stride=stride, padding=pad)
+    y = conv(T(x)).cpu().numpy()
+    ref = O.conv2d(x * a_in[None, :, None, None] + b_in[None, :, None, None], wt * a_out[:, None, None, None], bias, stride, pad)
+    if act:
+        ref = np.where(ref >= 0, ref, ref * (slope[None, :, None, None] if act == 1 else slope[0]))
+    assert y.shape == ref.shape
+    assert maxabs(y, ref) <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize('name,ci,co,st', [('unit_same', 64, 64, 1), ('unit_down', 64, 64, 2), ('unit_proj', 64, 128, 2)])
+def test_residual_units(name, ci, co, st):
+    from models.setgan.encoder.encoders.helpers import bottleneck_IR_SE
+    from synth_weights import synth_encoder_state_dict
+    u = bottleneck_IR_SE(ci, co, st).eval()
+    man = {('body.0.' + k): list(v.shape) for k, v in u.state_dict().items()}
+    sd = synth_encoder_state_dict(man, seed=5)
+    u.load_state_dict({k[len('body.0.'):]: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    u = u.to(DEV)
+    x = torch.from_numpy(np.random.RandomState(7).randn(2, ci, 20, 24).astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        assert maxabs(u.forward_hip(x).cpu().numpy(), golden('encoder')[name + '/y']) <= 2e-5
+
+
+def test_backbone_encoder():
+    from torch_utils import _sg3abi
+    g = golden('encoder')
+    enc = build_product_encoder(DEV)
+    x = torch.from_numpy(_input()).to(DEV)
+    n0 = _sg3abi.launch_count
+    with torch.no_grad():
+        codes = enc(x)
+        assert _sg3abi.launch_count - n0 >= 50 + 1 + 48, 'the fused HIP path did not run'
+        ref_path = enc._forward_torch(x)                      # same modules through torch / MIOpen
+    assert tuple(codes.shape) == (2, 16, 512)
+    assert maxabs(codes.cpu().numpy(), g['codes']) <= 2e-4
+    assert maxabs(codes.cpu().numpy(), ref_path.cpu().numpy()) <= 2e-3    # MIOpen's own fp32 path differs more than ours
+    # packed weights follow parameter changes after invalidation
+    with torch.no_grad():
+        enc.input_layer[1].bias.add_(0.5)
+        enc.invalidate_packed()
+        assert maxabs(enc(x).cpu().numpy(), enc._forward_torch(x).cpu().numpy()) <= 2e-3
+        assert maxabs(enc(x).cpu().numpy(), g['codes']) > 1e-3
