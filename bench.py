@@ -112,6 +112,43 @@ def cpu_baseline(cfg):
                 sample=f'1 image, {cfg} synthesis forward fp32, {dt:.1f} s on {O.num_threads()} OpenMP threads')
 
 
+def bench_inversion(G, device, rank, world, frames_per_gpu=16, restyle_steps=5, reps=2):
+    """Secondary measurement (BASELINE metric, second half): ReStyle-pSp inversion frames/s.  Every rank inverts its own
+    contiguous range of synthetic 256x256 frames (IR-SE50 encoder with seeded synthetic weights -> 5 refinement steps,
+    each one encoder forward + one FFHQ-1024 synthesis forward), then the final latents are all-gathered (RCCL)."""
+    import types
+    from models.setgan.encoder.psp3 import pSp
+    from sg3_runtime.sharded import ShardedInversion
+    from synth_weights import synth_encoder_state_dict
+    opts = types.SimpleNamespace(encoder_type='BackboneEncoder', input_nc=6, checkpoint_path=None, n_iters_per_batch=restyle_steps, resize_outputs=False)
+    net = pSp(opts, decoder=G)
+    man = {k: list(v.shape) for k, v in net.encoder.state_dict().items()}
+    net.encoder.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth_encoder_state_dict(man, seed=0).items()})
+    net = net.eval().requires_grad_(False).to(device)
+    n_frames = frames_per_gpu * world
+    frames = torch.from_numpy(np.random.RandomState(9).uniform(-1, 1, size=(n_frames, 3, 256, 256)).astype(np.float32)).to(device)
+    inv = ShardedInversion(net, opts, batch_size=frames_per_gpu)
+    inv.invert(frames)                                   # warm-up (packs the encoder weights)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lat, _ = inv.invert(frames)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert tuple(lat.shape) == (n_frames, 16, 512) and bool(torch.isfinite(lat).all())
+    return dict(metric='ReStyle-pSp video-inversion frames/sec', value=n_frames * reps / float(t.item()), unit='frames/s',
+                frames_per_gpu=frames_per_gpu, restyle_steps=restyle_steps, scaling='weak',
+                workload='IR-SE50 encoder + FFHQ-1024 config-T decoder, 5 ReStyle steps per frame, frames sharded over ranks, '
+                         'all-gather of [F,16,512] latents; synthetic weights')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -120,6 +157,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
     ap.add_argument('--config', default='T1024')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-inversion', action='store_true', help='skip the secondary ReStyle inversion measurement')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a captured hipGraph')
     args = ap.parse_args()
 
@@ -193,6 +231,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    inversion = None
+    if not args.no_inversion and args.config == 'T1024':
+        inversion = bench_inversion(G, device, rank, world)
+
     if rank == 0:
         total_bytes, _ = flrelu_algorithmic_bytes(G, args.batch)
         fl_ms = timer.total_ms('filtered_lrelu') / max(ksteps, 1)        # per step, all 15 launches
@@ -223,6 +265,7 @@ def main():
             'modconv': {'bound': 'mfma', 'tflops': conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                         'peak_fp32_mfma_tflops': 157.3, 'kernel_ms_per_step': conv_ms},
         }
+        out['inversion'] = inversion
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.config)
         else:

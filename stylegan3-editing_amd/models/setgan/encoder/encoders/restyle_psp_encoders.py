@@ -28,10 +28,14 @@ class BackboneEncoder(Module):
         self.style_count = n_styles
         self._packed = None
 
+    def _combine(self, per_style):
+        """[style_count x [N,512]] -> [N, style_count, 512] (the e4e variant overrides this with w0 + deltas)."""
+        return torch.stack(per_style, dim=1)
+
     # plain PyTorch definition (CPU, training)
     def _forward_torch(self, x):
         x = self.body(self.input_layer(x))
-        return torch.stack([style(x) for style in self.styles], dim=1)
+        return self._combine([style(x) for style in self.styles])
 
     def invalidate_packed(self):
         """Drop the packed / folded weights (call after changing parameters or BatchNorm statistics)."""
@@ -79,7 +83,7 @@ class BackboneEncoder(Module):
             for conv in pk['heads'][j]:
                 h = conv(h)
             outs.append(style.linear(h.reshape(-1, style.out_c)))
-        return torch.stack(outs, dim=1)
+        return self._combine(outs)
 
     def forward(self, x):
         if x.is_cuda and not self.training and not torch.is_grad_enabled():

@@ -107,3 +107,22 @@ def test_psp_and_run_on_batch_plumbing():
         imgs_u, _ = run_on_batch(inputs, net, opts, avg, landmarks_transform=tr)
         assert maxabs(imgs_u[0][1].numpy(), imgs[0][1].numpy()) <= 1e-5       # non-final steps: aligned output
         assert maxabs(imgs_u[0][2].numpy(), imgs[0][2].numpy()) > 1e-3        # final step: shifted (unaligned) output
+
+
+def test_e4e_progressive_encoder_combination():
+    """ProgressiveBackboneEncoder: same trunk/heads as the pSp backbone, combined as w0 + delta_i
+    (reference restyle_e4e_encoders.py:79-89); state_dict keys are the pSp backbone's."""
+    from models.setgan.encoder.e4e3 import e4e
+    from models.setgan.encoder.encoders.restyle_e4e_encoders import ProgressiveBackboneEncoder
+    enc = build_product_encoder()
+    prog = ProgressiveBackboneEncoder(50, 'ir_se', 16, types.SimpleNamespace(input_nc=6)).eval().requires_grad_(False)
+    prog.load_state_dict(enc.state_dict(), strict=True)
+    x = torch.from_numpy(_input()[:1])
+    with torch.no_grad():
+        a, b = enc(x), prog(x)
+        assert maxabs(b[:, 0].numpy(), a[:, 0].numpy()) <= 1e-6
+        assert maxabs(b[:, 5].numpy(), (a[:, 0] + a[:, 5]).numpy()) <= 1e-6
+        prog.set_progressive_stage(3)
+        c = prog(x)
+        assert maxabs(c[:, 3].numpy(), (a[:, 0] + a[:, 3]).numpy()) <= 1e-6 and maxabs(c[:, 4].numpy(), a[:, 0].numpy()) <= 1e-6
+    assert issubclass(e4e, torch.nn.Module) and e4e.forward is not None
