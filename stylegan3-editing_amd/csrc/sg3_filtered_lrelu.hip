@@ -100,6 +100,8 @@ template <int U, int D> struct StreamCfg {
     static constexpr int NL = (IWS + 63) / 64;          // global loads per lane per row
     static constexpr int SIN = NL * 64;                 // LDS floats for the input row
     static constexpr int SOUT = 4 + 256 + 16;           // LDS floats for the output row
+    static constexpr int RING_PITCH = 4 + 256 + 16;     // radial variant: 12 such rows form the ring
+    static constexpr int STAP = 144;                    // radial variant: 12x12 taps
     static constexpr int MAXTW = 120;
 };
 
@@ -144,7 +146,7 @@ struct WaveState {
     v2f tdP[Cfg::FD / 2];         // down taps (td[2m], td[2m+1]): V-down splats and H-down even/odd pairs
 };
 
-template <typename T, int U, int D, int VPH>
+template <typename T, int U, int D, int VPH, bool RADIAL>
 struct Stream {
     typedef StreamCfg<U, D> Cfg;
     typedef WaveState<T, U, D> State;
@@ -163,7 +165,7 @@ struct Stream {
     // one input row: H-up into window slot S, then U upsampled rows through lrelu into the down accumulators
     template <int S, int HEAD>
     static __device__ __forceinline__ void step(State& st, const StreamParams& p, const T* __restrict__ plane, T* __restrict__ oplane,
-                                                lds_f* sIn, lds_f* sOut, int i, int delta, int lane,
+                                                lds_f* sIn, lds_f* sOut, lds_f* sTap, int i, int delta, int lane,
                                                 int oy0, int oy1, int ox0, int oxN, bool pairStore) {
         // ---- input row -> LDS -> this lane's H-upsampled samples ----
         wave_lds_sync();                 // the previous row's sIn reads precede this row's writes
@@ -226,8 +228,49 @@ struct Stream {
 #pragma unroll
             for (int c = 0; c < 4; c++) a[c] = __builtin_amdgcn_fmed3f(a[c], -clampv, clampv);
             const v2f r0 = {a[0], a[1]}, r1 = {a[2], a[3]};
-            // scatter into the FD/D output rows this upsampled row belongs to
             const int kp = (VPH + j) % D;                      // down phase of this row
+            if (RADIAL) {
+                // ---- full 2-D down filter (config R): the activated row goes into a 12-row LDS ring; when the row that
+                // completes an output row (down phase D-1) has arrived, that output row is the 12x12 stride-2 correlation
+                // of the ring: per ring row one even/odd polyphase pass with that row's 12 taps (taps staged in LDS)
+                constexpr int RP = Cfg::RING_PITCH;
+                const int slotW = (S * U + j) % 12;            // ring slot of this upsampled row (6*U rows per loop trip)
+                lds_f* dstr = sOut + slotW * RP + (4 - delta) + 4 * lane;
+                dstr[0] = r0.x; dstr[1] = r0.y; dstr[2] = r1.x; dstr[3] = r1.y;
+                if (kp == D - 1) {
+                    const int uy = U * (i - 5) - (U - 1) + j + p.py0;
+                    const int oy = (uy - (Cfg::FD - 1)) / D;   // exact
+                    if (oy >= oy0 && oy < oy1) {               // wave-uniform
+                        wave_lds_sync();
+                        v2f y0 = splat(0.f), y1 = splat(0.f);
+#pragma unroll
+                        for (int ky = 0; ky < 12; ky++) {
+                            const int slotR = (slotW + 1 + ky) % 12;       // ky = 11 is the row just written
+                            const lds_v4f* src = reinterpret_cast<const lds_v4f*>(sOut + slotR * RP + 4 + 4 * lane);
+                            const lds_v4f* tp = reinterpret_cast<const lds_v4f*>(sTap + ky * 12);
+                            v2f pr[8], tq[6];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) { const v4f t = src[q]; pr[2 * q] = (v2f){t.x, t.y}; pr[2 * q + 1] = (v2f){t.z, t.w}; }
+#pragma unroll
+                            for (int q = 0; q < 3; q++) { const v4f t = tp[q]; tq[2 * q] = (v2f){t.x, t.y}; tq[2 * q + 1] = (v2f){t.z, t.w}; }
+#pragma unroll
+                            for (int q = 0; q < 6; q++) { y0 = fma2(pr[q], tq[q], y0); y1 = fma2(pr[q + 1], tq[q], y1); }
+                        }
+                        const float f0 = (y0.x + y0.y) * gain, f1 = (y1.x + y1.y) * gain;
+                        T* orow = oplane + (long long)oy * p.ysH + ox0;
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)orow, (short)0, oxN * (int)sizeof(T), 0x00020000);
+                        if (pairStore) {
+                            bufio<T>::st2(rs, 2 * lane * (int)sizeof(T), f0, f1);
+                        } else {
+                            bufio<T>::st1(rs, 2 * lane * (int)sizeof(T), f0);
+                            bufio<T>::st1(rs, (2 * lane + 1) * (int)sizeof(T), f1);
+                        }
+                        wave_lds_sync();
+                    }
+                }
+                continue;
+            }
+            // scatter into the FD/D output rows this upsampled row belongs to
             const int headNow = (HEAD + ((VPH + j) / D)) % 6;  // completions so far in this step shift the head
 #pragma unroll
             for (int r = 0; r < 6; r++) {
@@ -278,9 +321,10 @@ struct Stream {
 
     static __device__ __forceinline__ void run(const StreamParams& p) {
         static_assert(U % D == 0 && D == 2, "streaming kernel: down must be 2 and divide up");
-        __shared__ __attribute__((aligned(16))) float lds[Cfg::SIN + Cfg::SOUT];
+        __shared__ __attribute__((aligned(16))) float lds[Cfg::SIN + (RADIAL ? 12 * Cfg::RING_PITCH + Cfg::STAP : Cfg::SOUT)];
         lds_f* sIn = (lds_f*)lds;
-        lds_f* sOut = (lds_f*)lds + Cfg::SIN;
+        lds_f* sOut = (lds_f*)lds + Cfg::SIN;                               // output row, or the 12-row ring
+        lds_f* sTap = (lds_f*)lds + Cfg::SIN + 12 * Cfg::RING_PITCH;        // radial variant only
         const int lane = threadIdx.x;
 
         // XCD-aware renumbering: consecutive logical blocks (adjacent strips / chunks of one plane) share an XCD's L2
@@ -314,10 +358,23 @@ struct Stream {
             const float f1 = p.fu[p.flip ? 2 * m + 1 : Cfg::FU - 2 - 2 * m], f0 = p.fu[p.flip ? 2 * m : Cfg::FU - 1 - 2 * m];
             st.tuP[m] = (v2f){to_sgpr(f1 * gU), to_sgpr(f0 * gU)};
         }
+        if (RADIAL) {
+            // 12x12 correlation taps g[ky][kx] = fd[flip ? ky : 11-ky][flip ? kx : 11-kx] -> LDS (read back as wave-uniform
+            // broadcast b128 loads); the ring starts zeroed so that warm-up rows read defined values
+            for (int t = lane; t < 144; t += 64) {
+                const int ky = t / 12, kx = t % 12;
+                sTap[t] = p.fd[(p.flip ? ky : 11 - ky) * 12 + (p.flip ? kx : 11 - kx)];
+            }
+            for (int t = lane; t < 12 * Cfg::RING_PITCH; t += 64) sOut[t] = 0.f;
 #pragma unroll
-        for (int m = 0; m < Cfg::FD / 2; m++) {
-            const float f0 = p.fd[p.flip ? 2 * m : Cfg::FD - 1 - 2 * m], f1 = p.fd[p.flip ? 2 * m + 1 : Cfg::FD - 2 - 2 * m];
-            st.tdP[m] = (v2f){to_sgpr(f0), to_sgpr(f1)};
+            for (int m = 0; m < Cfg::FD / 2; m++) st.tdP[m] = splat(0.f);
+            wave_lds_sync();
+        } else {
+#pragma unroll
+            for (int m = 0; m < Cfg::FD / 2; m++) {
+                const float f0 = p.fd[p.flip ? 2 * m : Cfg::FD - 1 - 2 * m], f1 = p.fd[p.flip ? 2 * m + 1 : Cfg::FD - 2 - 2 * m];
+                st.tdP[m] = (v2f){to_sgpr(f0), to_sgpr(f1)};
+            }
         }
 
         // horizontal geometry: first upsampled column of the strip, shifted left by delta so that every lane's
@@ -349,20 +406,20 @@ struct Stream {
         constexpr int ADV = U / D;                               // output rows completed per input row
         int i = iFirst;
         for (int blk = 0; blk < nBlocks; blk++, i += 6) {
-            step<0, (0 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 0, delta, lane, oy0, oy1, ox0, oxN, pairStore);
-            step<1, (1 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 1, delta, lane, oy0, oy1, ox0, oxN, pairStore);
-            step<2, (2 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 2, delta, lane, oy0, oy1, ox0, oxN, pairStore);
-            step<3, (3 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 3, delta, lane, oy0, oy1, ox0, oxN, pairStore);
-            step<4, (4 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 4, delta, lane, oy0, oy1, ox0, oxN, pairStore);
-            step<5, (5 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 5, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<0, (0 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, sTap, i + 0, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<1, (1 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, sTap, i + 1, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<2, (2 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, sTap, i + 2, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<3, (3 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, sTap, i + 3, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<4, (4 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, sTap, i + 4, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<5, (5 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, sTap, i + 5, delta, lane, oy0, oy1, ox0, oxN, pairStore);
         }
     }
 };
 
-template <typename T, int U, int D, int VPH>
+template <typename T, int U, int D, int VPH, bool RADIAL>
 __global__ void __launch_bounds__(64)
 flrelu_stream_kernel(StreamParams p) {
-    Stream<T, U, D, VPH>::run(p);
+    Stream<T, U, D, VPH, RADIAL>::run(p);
 }
 
 // ---------------------------------------------------------------------------
@@ -399,7 +456,8 @@ flrelu_pointwise_kernel(PointParams p) {
 
 // ---------------------------------------------------------------------------
 static bool stream_supported(int up, int down, int fuW, int fuH, int fdW, int fdH) {
-    if (fuH != 0 || fdH != 0) return false;                   // separable only
+    if (fuH != 0) return false;                               // separable up filter
+    if (fdH != 0 && fdH != 12) return false;                  // separable, or full 12x12 (radial) down filter
     if (down != 2 || fdW != 12) return false;
     return (up == 2 && fuW == 12) || (up == 4 && fuW == 24);
 }
@@ -444,9 +502,14 @@ static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
 
     const int vph = (((q.py0 - (q.up - 1)) % q.down) + q.down) % q.down;
     dim3 g((unsigned)total), b(64);
-#define SG3_STREAM_LAUNCH(U, V) hipLaunchKernelGGL((flrelu_stream_kernel<T, U, 2, V>), g, b, 0, st, p)
-    if (q.up == 2) { if (vph == 0) SG3_STREAM_LAUNCH(2, 0); else SG3_STREAM_LAUNCH(2, 1); }
-    else           { if (vph == 0) SG3_STREAM_LAUNCH(4, 0); else SG3_STREAM_LAUNCH(4, 1); }
+#define SG3_STREAM_LAUNCH(U, V, R) hipLaunchKernelGGL((flrelu_stream_kernel<T, U, 2, V, R>), g, b, 0, st, p)
+    if (q.fdH == 0) {
+        if (q.up == 2) { if (vph == 0) SG3_STREAM_LAUNCH(2, 0, false); else SG3_STREAM_LAUNCH(2, 1, false); }
+        else           { if (vph == 0) SG3_STREAM_LAUNCH(4, 0, false); else SG3_STREAM_LAUNCH(4, 1, false); }
+    } else {
+        if (q.up == 2) { if (vph == 0) SG3_STREAM_LAUNCH(2, 0, true); else SG3_STREAM_LAUNCH(2, 1, true); }
+        else           { if (vph == 0) SG3_STREAM_LAUNCH(4, 0, true); else SG3_STREAM_LAUNCH(4, 1, true); }
+    }
 #undef SG3_STREAM_LAUNCH
     SG3_LAUNCH_CHECK("flrelu_stream_kernel");
     return SG3_OK;

@@ -85,6 +85,28 @@ def test_filtered_lrelu_stream_kernel_sizes(shape, up, taps, pad):
     assert maxabs(y.cpu().numpy(), ref) <= 2e-5
 
 
+@pytest.mark.parametrize('shape,up,taps,pad', [
+    ((1, 2, 148, 148), 2, 12, [11, 10, 11, 10]),       # config-R up 2 (1x1 conv: no conv halo), 2 strips
+    ((2, 3, 84, 84), 4, 24, [-2, -5, -2, -5]),          # config-R up 4
+    ((1, 1, 276, 300), 4, 24, [-2, -5, -2, -5]),        # several strips and row chunks
+    ((1, 2, 532, 200), 2, 12, [11, 10, 11, 10]),
+])
+def test_filtered_lrelu_radial_stream_kernel_sizes(shape, up, taps, pad):
+    """Streaming kernel with the full 12x12 radial down filter (config R) across strip / chunk boundaries."""
+    from oracle import oracle as O
+    fs = 64
+    fu = O.design_lowpass_filter(taps, 4.0, 8.0, fs * up / 2)
+    fd = O.design_lowpass_filter(12, 5.0, 9.0, fs, radial=True)
+    fd = (fd + 0.01 * np.random.RandomState(8).rand(12, 12).astype(np.float32)).astype(np.float32)     # break the symmetry: exposes flips
+    x = rand(3, *shape); b = rand(4, shape[1])
+    for flip in (False, True):
+        c = dict(up=up, down=2, padding=pad, gain=float(np.sqrt(2)), slope=0.2, clamp=256, flip=flip)
+        y = _flrelu(c, T(x), T(b), T(fu), T(fd))
+        ref = O.filtered_lrelu(x, fu, fd, b, up, 2, pad, c['gain'], 0.2, 256, flip)
+        assert tuple(y.shape) == ref.shape
+        assert maxabs(y.cpu().numpy(), ref) <= 2e-5
+
+
 def test_filtered_lrelu_strided_input_and_bias():
     """Element strides are honoured (reference filtered_lrelu.cpp:127-134): channel-sliced and row-padded views."""
     from oracle import oracle as O
