@@ -33,6 +33,8 @@ template <> struct ConvK<3> { static constexpr int TAPS = 9, KC = 8; };
 template <> struct ConvK<1> { static constexpr int TAPS = 1, KC = 16; };
 
 static inline int packed_kc(int k) { return k == 3 ? ConvK<3>::KC : ConvK<1>::KC; }
+// 16-channel chunks of the f16x3 packing; 1x1 kernels stage two chunks per step, so their count is padded to even
+static inline int f16x3_chunks(int I, int k) { const int c = (I + 15) / 16; return k == 1 ? (c + 1) / 2 * 2 : c; }
 
 struct ConvParams {
     const void* x; const float* wp; const float* sIn; const float* dcoef; void* out;
@@ -404,6 +406,173 @@ modconv_f16x3_kernel(ConvParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// Split-precision variant for 1x1 kernels (config R): a plain GEMM  out[O, pixels] = Wn[O, I] * (sIn * x)[I, pixels].
+// Each staged input element is used once per output-channel tile (not 9 times as in the 3x3 kernel), so the tile is
+// larger along M (128 x 256 pixels, eight waves, wave tile 64 x 64) to keep the L2 -> LDS stream at ~44 FLOP/B, two
+// 16-channel K steps are staged per barrier, and the LDS image is double-buffered: one barrier per 32 input channels.
+// LDS per buffer: A rows of (hi16|lo16) x 2 halfs + 8 halfs of padding; B as planes [k-step][channel-half][hi|lo][pixel][8].
+template <typename T, int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(512)
+modconv1_f16x3_kernel(ConvParams p) {
+    constexpr int KSUB = 2, KC = 16 * KSUB;
+    constexpr int BM = WM * TM * 32;
+    constexpr int ROWS = WN * TN;
+    constexpr int NPIX = ROWS * 32;
+    constexpr int AS = KSUB * 32 + 8;                  // halfs per A row in LDS
+    constexpr int AROW_V = KSUB * 4;                   // 16-byte vectors per packed A row and stage
+    constexpr int A_VEC = BM * AROW_V;
+    constexpr int A_PER = (A_VEC + 511) / 512;
+    constexpr int BPLANE = NPIX * 8;                   // halfs per (k-step, channel-half, part) plane
+    constexpr int BUF = BM * AS + KSUB * 4 * BPLANE;   // halfs per LDS buffer
+    static_assert(WM * WN == 8, "8 waves per workgroup");
+    static_assert(NPIX == 256, "one patch pixel per thread pair");
+
+    extern __shared__ __attribute__((aligned(16))) _Float16 smh[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int kh = wave >> 2;                          // channel half (of each 16) this thread stages: wave-uniform
+
+    int bid = blockIdx.x;
+    {
+        const int nb = p.totalBlocks, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int mt = bid % p.mTiles; bid /= p.mTiles;
+    const int xt = bid % p.xTiles; bid /= p.xTiles;
+    const int yt = bid % p.yTiles; const int n = bid / p.yTiles;
+    const int o0 = mt * BM, x0 = xt * 32, y0 = yt * ROWS;
+
+    const unsigned HWb = (unsigned)(p.H * p.W) * (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const T*)p.x + (size_t)n * p.I * p.H * p.W), (short)0, (int)((unsigned)p.I * HWb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.wp, (short)0, (int)((unsigned)p.O * (unsigned)p.nch * (unsigned)(AROW_V * 16)), 0x00020000);
+    // A: vector v of the stage -> row v / AROW_V, 16-byte column v % AROW_V
+    unsigned aG[A_PER]; int aL[A_PER];
+#pragma unroll
+    for (int q = 0; q < A_PER; q++) {
+        const int v = tid + 512 * q, row = v / AROW_V, col = v % AROW_V;
+        const bool ok = v < A_VEC && o0 + row < p.O;
+        aG[q] = ok ? ((unsigned)(o0 + row) * (unsigned)p.nch * (AROW_V * 16) + col * 16) : 0x80000000u;
+        aL[q] = v < A_VEC ? row * AS + col * 8 : -1;
+    }
+    // B: this thread's patch pixel
+    const int e = tid & 255;
+    unsigned bG;
+    {
+        const int px = e & 31, py = e >> 5, gy = y0 + py, gx = x0 + px;
+        bG = (gy < p.H && gx < p.W) ? (unsigned)(gy * p.W + gx) * (unsigned)sizeof(T) : 0x80000000u;
+    }
+    const float* sInN = p.sIn + (size_t)n * p.I;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; a++)
+#pragma unroll
+        for (int b = 0; b < TN; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    u32x4 ra[A_PER];
+    float rb[KSUB][8];
+
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int q = 0; q < A_PER; q++)
+            ra[q] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)(aG[q] + (unsigned)ch * (AROW_V * 16)), 0, 0);
+#pragma unroll
+        for (int sub = 0; sub < KSUB; sub++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int ci = ch * KC + sub * 16 + kh * 8 + c;                 // wave-uniform
+                const unsigned coff = ci < p.I ? (unsigned)ci * HWb : 0u;
+                const float sc = ci < p.I ? sInN[ci] : 0.f;
+                rb[sub][c] = bufld<T>::ld(xr, bG, coff) * sc;
+            }
+    };
+    auto stage = [&](_Float16* buf) {
+        _Float16* sA = buf;
+        _Float16* sB = buf + BM * AS;
+#pragma unroll
+        for (int q = 0; q < A_PER; q++)
+            if (aL[q] >= 0) *reinterpret_cast<u32x4*>(sA + aL[q]) = ra[q];
+#pragma unroll
+        for (int sub = 0; sub < KSUB; sub++) {
+            v2h h[4], l[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) split2(rb[sub][2 * c], rb[sub][2 * c + 1], h[c], l[c]);
+            _Float16* dst = sB + ((sub * 2 + kh) * 2) * BPLANE + e * 8;
+            *reinterpret_cast<v8h*>(dst) = __builtin_shufflevector(__builtin_shufflevector(h[0], h[1], 0, 1, 2, 3), __builtin_shufflevector(h[2], h[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
+            *reinterpret_cast<v8h*>(dst + BPLANE) = __builtin_shufflevector(__builtin_shufflevector(l[0], l[1], 0, 1, 2, 3), __builtin_shufflevector(l[2], l[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+    struct Frags { v8h ah[TM], al[TM], bh[TN], bl[TN]; };
+    auto load_frags = [&](Frags& f, const _Float16* buf, int sub) {
+        const _Float16* sA = buf;
+        const _Float16* sB = buf + BM * AS;
+#pragma unroll
+        for (int a = 0; a < TM; a++) {
+            const _Float16* src = sA + ((wm * TM + a) * 32 + li) * AS + sub * 32 + lh * 8;
+            f.ah[a] = *reinterpret_cast<const v8h*>(src);
+            f.al[a] = *reinterpret_cast<const v8h*>(src + 16);
+        }
+#pragma unroll
+        for (int b = 0; b < TN; b++) {
+            const _Float16* src = sB + ((sub * 2 + lh) * 2) * BPLANE + ((wn * TN + b) * 32 + li) * 8;
+            f.bh[b] = *reinterpret_cast<const v8h*>(src);
+            f.bl[b] = *reinterpret_cast<const v8h*>(src + BPLANE);
+        }
+    };
+    auto mfma_step = [&](const Frags& f) {
+#pragma unroll
+        for (int a = 0; a < TM; a++)
+#pragma unroll
+            for (int b = 0; b < TN; b++) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[a], f.bh[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bl[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bh[b], acc[a][b], 0, 0, 0);
+            }
+    };
+
+    fetch(0);
+    stage(smh);
+    __syncthreads();
+    for (int ch = 0; ch < p.nch; ch++) {
+        const _Float16* cur = smh + (ch & 1) * BUF;
+        const bool more = ch + 1 < p.nch;
+        if (more) fetch(ch + 1);
+        Frags f0, f1;
+        load_frags(f0, cur, 0);
+        load_frags(f1, cur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(f0);
+        mfma_step(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) stage(smh + ((ch + 1) & 1) * BUF);       // the other buffer: its readers passed the previous barrier
+        __syncthreads();
+    }
+
+    T* outp = (T*)p.out + (size_t)n * p.O * p.outH * p.outW;
+    const int gx = x0 + li;
+#pragma unroll
+    for (int a = 0; a < TM; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int o = o0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (o >= p.O) continue;
+            const float d = p.dcoef[(size_t)n * p.O + o];
+#pragma unroll
+            for (int b = 0; b < TN; b++) {
+                const int gy = y0 + wn * TN + b;
+                if (gy < p.outH && gx < p.outW)
+                    io<T>::st(outp + ((size_t)o * p.outH + gy) * p.outW + gx, acc[a][b][r] * d);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------
 // 1x1 kernels with very few output channels (the ToRGB layer: 32 -> 3): HBM-bound, no matrix cores.
 // out[n,o,p] = dcoef[n,o] * sum_i wn[o,i] * sIn[n,i] * x[n,i,p]; a thread owns 4 consecutive pixels (16-byte loads
 // per channel plane), the modulated weights sit in LDS.
@@ -638,6 +807,34 @@ static int dispatch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     return launch_conv_f16x3<T, 1, 4, 2, 2>(q, st);                                 //  64 x (8 rows x 32)
 }
 
+template <typename T, int WM, int WN, int TM, int TN>
+static int launch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, ROWS = WN * TN;
+    constexpr size_t ldsBytes = 2 * ((size_t)BM * (2 * 32 + 8) + 8 * (size_t)ROWS * 32 * 8) * sizeof(_Float16);
+    ConvParams p;
+    p.x = q.x; p.wp = q.wPacked; p.sIn = q.sIn; p.dcoef = q.dcoef; p.out = q.out;
+    p.N = q.N; p.I = q.I; p.O = q.O; p.H = q.H; p.W = q.W; p.pad = 0;
+    p.outH = q.H; p.outW = q.W;
+    p.nch = f16x3_chunks(q.I, 1) / 2;                  // stages of 32 channels
+    p.xTiles = ceil_div(p.outW, 32); p.yTiles = ceil_div(p.outH, ROWS); p.mTiles = ceil_div(q.O, BM);
+    const long long total = (long long)p.xTiles * p.yTiles * p.mTiles * q.N;
+    if (total > 0x7fffffffLL) { set_error("modulated_conv2d: grid too large"); return SG3_BAD_ARG; }
+    p.totalBlocks = (int)total;
+    auto kern = modconv1_f16x3_kernel<T, WM, WN, TM, TN>;
+    if (ldsBytes > 64 * 1024)
+        SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), ldsBytes, st, p);
+    SG3_LAUNCH_CHECK("modconv1_f16x3_kernel");
+    return SG3_OK;
+}
+
+template <typename T>
+static int dispatch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
+    const int t64 = ceil_div(q.O, 64) * 64, t128 = ceil_div(q.O, 128) * 128;
+    if (t64 < t128) return launch_conv1_f16x3<T, 1, 8, 2, 1>(q, st);              //  64 x (8 rows x 32)
+    return launch_conv1_f16x3<T, 2, 4, 2, 2>(q, st);                              // 128 x (8 rows x 32)
+}
+
 } // namespace sg3
 
 extern "C" {
@@ -645,8 +842,7 @@ extern "C" {
 int64_t sg3_modconv_packed_floats(int O, int I, int k, int precision) {
     if (O <= 0 || I <= 0 || (k != 1 && k != 3)) return 0;
     if (precision == SG3_CONV_F16X3) {
-        if (k != 3) return 0;
-        return (int64_t)O * sg3::ceil_div(I, 16) * 9 * 16;          // 32 halfs = 16 floats per (chunk, tap)
+        return (int64_t)O * sg3::f16x3_chunks(I, k) * (k * k) * 16;   // 32 halfs = 16 floats per (chunk, tap)
     }
     const int kc = sg3::packed_kc(k);
     return (int64_t)O * sg3::ceil_div(I, kc) * (k * k) * kc;
@@ -663,11 +859,11 @@ int sg3_modulated_conv2d_prep(const sg3_modconv_prep_params* p, void* stream) {
     SG3_REQUIRE((size_t)p->I * 2 * sizeof(float) <= 48 * 1024, "modulated_conv2d_prep: too many input channels");
     SG3_REQUIRE(p->precision == SG3_CONV_FP32 || p->precision == SG3_CONV_F16X3, "modulated_conv2d_prep: bad precision");
     if (p->precision == SG3_CONV_F16X3) {
-        SG3_REQUIRE(p->k == 3, "modulated_conv2d_prep: f16x3 needs a 3x3 kernel");
         SG3_REQUIRE(p->xBound > 0.f && p->dcoef, "modulated_conv2d_prep: f16x3 needs xBound > 0 and a dcoef buffer");
     }
     hipStream_t st = (hipStream_t)stream;
-    const int kc = packed_kc(p->k), nch = ceil_div(p->I, p->precision == SG3_CONV_F16X3 ? 16 : kc);
+    const int kc = packed_kc(p->k);
+    const int nch = p->precision == SG3_CONV_F16X3 ? f16x3_chunks(p->I, p->k) : ceil_div(p->I, kc);
     hipLaunchKernelGGL(modconv_prep_w_kernel, dim3(p->O), dim3(256), 0, st, *p, kc, nch);
     SG3_LAUNCH_CHECK("modconv_prep_w_kernel");
     hipLaunchKernelGGL(modconv_prep_s_kernel, dim3(p->N), dim3(256), (size_t)p->I * 2 * sizeof(float), st, *p);
@@ -685,8 +881,10 @@ int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream) {
     SG3_REQUIRE(p->dtype == SG3_F32 || p->dtype == SG3_F16, "modulated_conv2d: unsupported dtype");
     hipStream_t st = (hipStream_t)stream;
     if (p->precision == SG3_CONV_F16X3) {
-        SG3_REQUIRE(p->k == 3 && p->dcoef, "modulated_conv2d: f16x3 needs a 3x3 kernel and dcoef");
+        SG3_REQUIRE(p->dcoef, "modulated_conv2d: f16x3 needs dcoef");
+        SG3_REQUIRE(p->k == 3 || p->pad == 0, "modulated_conv2d: f16x3 1x1 kernels take no padding");
         SG3_REQUIRE((int64_t)p->I * p->H * p->W * 4 < (int64_t)1 << 31, "modulated_conv2d: f16x3 needs a sample below 2 GiB (32-bit offsets)");
+        if (p->k == 1) return p->dtype == SG3_F32 ? dispatch_conv1_f16x3<float>(*p, st) : dispatch_conv1_f16x3<_Float16>(*p, st);
         return p->dtype == SG3_F32 ? dispatch_conv_f16x3<float>(*p, st) : dispatch_conv_f16x3<_Float16>(*p, st);
     }
     SG3_REQUIRE(p->precision == SG3_CONV_FP32, "modulated_conv2d: bad precision");

@@ -23,11 +23,11 @@ import torch
 from .. import _sg3abi as abi
 from .. import misc
 
-# Arithmetic of the implicit GEMM for 3x3 kernels when the caller supplies a bound on |x| (`x_bound`):
+# Arithmetic of the implicit GEMM when the caller supplies a bound on |x| (`x_bound`):
 #   'f16x3' : fp16 hi/lo operand split, three fp16 MFMAs per K step, fp32 accumulation (fp32-equivalent: every
 #             retained product is exact, the dropped lo*lo term is 2^-22 relative) at 5.3x the fp32 MFMA rate;
 #   'fp32'  : v_mfma_f32_32x32x2_f32, exact fp32 products.
-# Calls without a bound (and all 1x1 kernels) always use 'fp32'.
+# Calls without a bound always use 'fp32'.
 precision = 'f16x3'
 
 
@@ -70,7 +70,7 @@ def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None):
         else:
             gmode, g = 3, g.expand(n, ci).contiguous()
         gptr = g
-    split = precision == 'f16x3' and k == 3 and x_bound is not None and x_bound > 0
+    split = precision == 'f16x3' and (k == 3 or padding == 0) and x_bound is not None and x_bound > 0
     prec = abi.SG3_CONV_F16X3 if split else abi.SG3_CONV_FP32
     wn = torch.empty([int(lib.sg3_modconv_packed_floats(co, ci, k, prec))], dtype=torch.float32, device=dev)
     wsq = torch.empty([co, ci], dtype=torch.float32, device=dev)

@@ -274,6 +274,35 @@ def test_modulated_conv2d_split_precision(n, ci, co, h):
     assert maxabs(y.cpu().numpy(), ref2) <= 2e-6 * float(np.abs(ref2).max())
 
 
+@pytest.mark.parametrize('n,ci,co,h', [(2, 645, 406, 20), (1, 1024, 1024, 12), (2, 161, 102, 70), (1, 64, 64, 33), (3, 102, 64, 50), (1, 17, 200, 9)])
+def test_modulated_conv2d_split_precision_1x1(n, ci, co, h):
+    """Config-R 1x1 kernels through the split-precision GEMM kernel (odd channel counts, tile tails, fp16 I/O)."""
+    from oracle import oracle as O
+    from torch_utils.ops import modulated_conv as mc
+    x = np.clip(rand(81, n, ci, h, h + 3) * 40, -256, 256).astype(np.float32); w = rand(82, co, ci, 1, 1); s = rand(83, n, ci) + 1
+    ref = O.modulated_conv2d(x.astype(np.float64), w.astype(np.float64), s.astype(np.float64), True, 0, 0.8)
+    scale = max(1.0, float(np.abs(ref).max()))
+    errs = {}
+    for prec in ('f16x3', 'fp32'):
+        mc.precision = prec
+        try:
+            y = mc.modulated_conv2d(T(x), T(w), T(s), demodulate=True, padding=0, input_gain=torch.tensor(0.8, device=DEV), x_bound=256.0)
+        finally:
+            mc.precision = 'f16x3'
+        assert tuple(y.shape) == ref.shape
+        errs[prec] = maxabs(y.cpu().numpy(), ref) / scale
+    print('relative max errors vs fp64:', errs)
+    assert errs['fp32'] <= 5e-6 and errs['f16x3'] <= 5e-6, errs
+    s_big = (s * 1000).astype(np.float32)
+    y = mc.modulated_conv2d(T(x), T(w), T(s_big), demodulate=False, padding=0, input_gain=None, x_bound=256.0)
+    ref2 = O.modulated_conv2d(x.astype(np.float64), w.astype(np.float64), s_big.astype(np.float64), False, 0, None)
+    assert bool(torch.isfinite(y).all())
+    assert maxabs(y.cpu().numpy(), ref2) <= 2e-6 * float(np.abs(ref2).max())
+    yh = mc.modulated_conv2d(T(x.astype(np.float16)), T(w), T(s), demodulate=True, padding=0, input_gain=None, x_bound=256.0)
+    refh = O.modulated_conv2d(x.astype(np.float16).astype(np.float64), w.astype(np.float64), s.astype(np.float64), True, 0, None)
+    assert yh.dtype == torch.float16 and maxabs(yh.float().cpu().numpy(), refh) <= 2e-3 * max(1.0, float(np.abs(refh).max()))
+
+
 def test_modulated_conv2d_fp16_and_grad():
     from oracle import oracle as O
     from models.stylegan3.networks_stylegan3 import modulated_conv2d
