@@ -92,6 +92,41 @@ __device__ __forceinline__ v2f mul_tap(v2f a, v2f tapPair) {
     return r;
 }
 
+// Radial (2-D) down filter taps: correlation taps g[k][x] = fd[flip ? k : 11-k][flip ? x : 11-x].  A filter row (12 taps)
+// is fetched through the scalar cache into three SGPR quads; without flip the row sits reversed in memory and the
+// packed FMA swaps the halves of its scalar pair (op_sel) instead of spending instructions on it.  The loads are
+// explicit asm: left to the compiler they are hoisted (constant memory) and spill the scalar file.
+struct TapRow { v4f a, b, c; };
+__device__ __forceinline__ void radial_row_issue(TapRow& t, const float* fd, int row) {
+    const float* src = fd + row * 12;
+    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20"
+                 : "=&s"(t.a), "=&s"(t.b), "=&s"(t.c) : "s"(src));
+}
+__device__ __forceinline__ void radial_row_wait(TapRow& t) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t.a), "+s"(t.b), "+s"(t.c));
+}
+// pair (g[k][2q], g[k][2q+1]) of the row (memory pair q with flip; memory pair 5-q, halves swapped, without)
+template <bool FLIP>
+__device__ __forceinline__ v2f radial_pair(const TapRow& t, int q) {
+    const int j = FLIP ? q : 5 - q;
+    const v4f v = j < 2 ? t.a : (j < 4 ? t.b : t.c);
+    return (j & 1) ? (v2f){v.z, v.w} : (v2f){v.x, v.y};
+}
+template <bool FLIP>
+__device__ __forceinline__ v2f radial_fma(v2f a, v2f tq, v2f acc) {
+    v2f r;
+    if (FLIP) asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(tq), "v"(acc));
+    else      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "s"(tq), "v"(acc));
+    return r;
+}
+template <bool FLIP>
+__device__ __forceinline__ v2f radial_mul(v2f a, v2f tq) {
+    v2f r;
+    if (FLIP) asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(tq));
+    else      asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "s"(tq));
+    return r;
+}
+
 template <int U, int D> struct StreamCfg {
     static constexpr int FU = 6 * U, FD = 6 * D;
     static constexpr int CPL = 4;                       // upsampled columns per lane
@@ -100,8 +135,6 @@ template <int U, int D> struct StreamCfg {
     static constexpr int NL = (IWS + 63) / 64;          // global loads per lane per row
     static constexpr int SIN = NL * 64;                 // LDS floats for the input row
     static constexpr int SOUT = 4 + 256 + 16;           // LDS floats for the output row
-    static constexpr int RING_PITCH = 4 + 256 + 16;     // radial variant: 12 such rows form the ring
-    static constexpr int STAP = 144;                    // radial variant: 12x12 taps
     static constexpr int MAXTW = 120;
 };
 
@@ -146,7 +179,7 @@ struct WaveState {
     v2f tdP[Cfg::FD / 2];         // down taps (td[2m], td[2m+1]): V-down splats and H-down even/odd pairs
 };
 
-template <typename T, int U, int D, int VPH, bool RADIAL>
+template <typename T, int U, int D, int VPH, int RADIAL>
 struct Stream {
     typedef StreamCfg<U, D> Cfg;
     typedef WaveState<T, U, D> State;
@@ -165,7 +198,7 @@ struct Stream {
     // one input row: H-up into window slot S, then U upsampled rows through lrelu into the down accumulators
     template <int S, int HEAD>
     static __device__ __forceinline__ void step(State& st, const StreamParams& p, const T* __restrict__ plane, T* __restrict__ oplane,
-                                                lds_f* sIn, lds_f* sOut, lds_f* sTap, int i, int delta, int lane,
+                                                lds_f* sIn, lds_f* sOut, int i, int delta, int lane,
                                                 int oy0, int oy1, int ox0, int oxN, bool pairStore) {
         // ---- input row -> LDS -> this lane's H-upsampled samples ----
         wave_lds_sync();                 // the previous row's sIn reads precede this row's writes
@@ -230,32 +263,47 @@ struct Stream {
             const v2f r0 = {a[0], a[1]}, r1 = {a[2], a[3]};
             const int kp = (VPH + j) % D;                      // down phase of this row
             if (RADIAL) {
-                // ---- full 2-D down filter (config R): the activated row goes into a 12-row LDS ring; when the row that
-                // completes an output row (down phase D-1) has arrived, that output row is the 12x12 stride-2 correlation
-                // of the ring: per ring row one even/odd polyphase pass with that row's 12 taps (taps staged in LDS)
-                constexpr int RP = Cfg::RING_PITCH;
-                const int slotW = (S * U + j) % 12;            // ring slot of this upsampled row (6*U rows per loop trip)
-                lds_f* dstr = sOut + slotW * RP + (4 - delta) + 4 * lane;
+                // ---- full 2-D down filter (config R): the activated row is exchanged through LDS once (each lane reads
+                // the 16 samples under its two output columns) and scattered into the six output rows it belongs to, one
+                // even/odd polyphase pass per output row with that row's 12 taps.  The 144 taps do not fit the scalar
+                // registers: they stream through the scalar cache (s_load) as SGPR pairs, off the LDS and VALU paths.
+                lds_f* dstr = sOut + (4 - delta) + 4 * lane;
                 dstr[0] = r0.x; dstr[1] = r0.y; dstr[2] = r1.x; dstr[3] = r1.y;
+                wave_lds_sync();
+                const lds_v4f* srcr = reinterpret_cast<const lds_v4f*>(sOut + 4 + 4 * lane);
+                v2f pr[8];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const v4f t = srcr[q]; pr[2 * q] = (v2f){t.x, t.y}; pr[2 * q + 1] = (v2f){t.z, t.w}; }
+                wave_lds_sync();
+                const int headR = (HEAD + ((VPH + j) / D)) % 6;
+                constexpr bool FLIPPED = RADIAL == 2;
+                TapRow rowA, rowB;                                 // filter rows in flight: the next one loads under this one's FMAs
+                radial_row_issue(rowA, p.fd, FLIPPED ? kp : 11 - kp);
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    const int slot = (headR + 5 - r) % 6;          // r = 5: oldest output row (completes first)
+                    const int k = kp + r * D;                      // filter row of this upsampled row in that output row
+                    TapRow& cur = (r & 1) ? rowB : rowA;
+                    TapRow& nxt = (r & 1) ? rowA : rowB;
+                    radial_row_wait(cur);
+                    if (r < 5) radial_row_issue(nxt, p.fd, FLIPPED ? k + D : 11 - (k + D));
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        const v2f tq = radial_pair<FLIPPED>(cur, q);
+                        if (k == 0 && q == 0) {
+                            st.acc[slot][0] = radial_mul<FLIPPED>(pr[0], tq);
+                            st.acc[slot][1] = radial_mul<FLIPPED>(pr[1], tq);
+                        } else {
+                            st.acc[slot][0] = radial_fma<FLIPPED>(pr[q], tq, st.acc[slot][0]);
+                            st.acc[slot][1] = radial_fma<FLIPPED>(pr[q + 1], tq, st.acc[slot][1]);
+                        }
+                    }
+                }
                 if (kp == D - 1) {
                     const int uy = U * (i - 5) - (U - 1) + j + p.py0;
-                    const int oy = (uy - (Cfg::FD - 1)) / D;   // exact
-                    if (oy >= oy0 && oy < oy1) {               // wave-uniform
-                        wave_lds_sync();
-                        v2f y0 = splat(0.f), y1 = splat(0.f);
-#pragma unroll
-                        for (int ky = 0; ky < 12; ky++) {
-                            const int slotR = (slotW + 1 + ky) % 12;       // ky = 11 is the row just written
-                            const lds_v4f* src = reinterpret_cast<const lds_v4f*>(sOut + slotR * RP + 4 + 4 * lane);
-                            const lds_v4f* tp = reinterpret_cast<const lds_v4f*>(sTap + ky * 12);
-                            v2f pr[8], tq[6];
-#pragma unroll
-                            for (int q = 0; q < 4; q++) { const v4f t = src[q]; pr[2 * q] = (v2f){t.x, t.y}; pr[2 * q + 1] = (v2f){t.z, t.w}; }
-#pragma unroll
-                            for (int q = 0; q < 3; q++) { const v4f t = tp[q]; tq[2 * q] = (v2f){t.x, t.y}; tq[2 * q + 1] = (v2f){t.z, t.w}; }
-#pragma unroll
-                            for (int q = 0; q < 6; q++) { y0 = fma2(pr[q], tq[q], y0); y1 = fma2(pr[q + 1], tq[q], y1); }
-                        }
+                    const int oy = (uy - (Cfg::FD - 1)) / D;       // exact
+                    if (oy >= oy0 && oy < oy1) {                   // wave-uniform
+                        const v2f y0 = st.acc[headR][0], y1 = st.acc[headR][1];
                         const float f0 = (y0.x + y0.y) * gain, f1 = (y1.x + y1.y) * gain;
                         T* orow = oplane + (long long)oy * p.ysH + ox0;
                         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)orow, (short)0, oxN * (int)sizeof(T), 0x00020000);
@@ -265,7 +313,6 @@ struct Stream {
                             bufio<T>::st1(rs, 2 * lane * (int)sizeof(T), f0);
                             bufio<T>::st1(rs, (2 * lane + 1) * (int)sizeof(T), f1);
                         }
-                        wave_lds_sync();
                     }
                 }
                 continue;
@@ -321,10 +368,9 @@ struct Stream {
 
     static __device__ __forceinline__ void run(const StreamParams& p) {
         static_assert(U % D == 0 && D == 2, "streaming kernel: down must be 2 and divide up");
-        __shared__ __attribute__((aligned(16))) float lds[Cfg::SIN + (RADIAL ? 12 * Cfg::RING_PITCH + Cfg::STAP : Cfg::SOUT)];
+        __shared__ __attribute__((aligned(16))) float lds[Cfg::SIN + Cfg::SOUT];
         lds_f* sIn = (lds_f*)lds;
-        lds_f* sOut = (lds_f*)lds + Cfg::SIN;                               // output row, or the 12-row ring
-        lds_f* sTap = (lds_f*)lds + Cfg::SIN + 12 * Cfg::RING_PITCH;        // radial variant only
+        lds_f* sOut = (lds_f*)lds + Cfg::SIN;                               // row exchanged for the horizontal down pass
         const int lane = threadIdx.x;
 
         // XCD-aware renumbering: consecutive logical blocks (adjacent strips / chunks of one plane) share an XCD's L2
@@ -359,16 +405,8 @@ struct Stream {
             st.tuP[m] = (v2f){to_sgpr(f1 * gU), to_sgpr(f0 * gU)};
         }
         if (RADIAL) {
-            // 12x12 correlation taps g[ky][kx] = fd[flip ? ky : 11-ky][flip ? kx : 11-kx] -> LDS (read back as wave-uniform
-            // broadcast b128 loads); the ring starts zeroed so that warm-up rows read defined values
-            for (int t = lane; t < 144; t += 64) {
-                const int ky = t / 12, kx = t % 12;
-                sTap[t] = p.fd[(p.flip ? ky : 11 - ky) * 12 + (p.flip ? kx : 11 - kx)];
-            }
-            for (int t = lane; t < 12 * Cfg::RING_PITCH; t += 64) sOut[t] = 0.f;
 #pragma unroll
-            for (int m = 0; m < Cfg::FD / 2; m++) st.tdP[m] = splat(0.f);
-            wave_lds_sync();
+            for (int m = 0; m < Cfg::FD / 2; m++) st.tdP[m] = splat(0.f);      // unused: the 12x12 taps stream from the scalar cache
         } else {
 #pragma unroll
             for (int m = 0; m < Cfg::FD / 2; m++) {
@@ -406,17 +444,17 @@ struct Stream {
         constexpr int ADV = U / D;                               // output rows completed per input row
         int i = iFirst;
         for (int blk = 0; blk < nBlocks; blk++, i += 6) {
-            step<0, (0 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, sTap, i + 0, delta, lane, oy0, oy1, ox0, oxN, pairStore);
-            step<1, (1 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, sTap, i + 1, delta, lane, oy0, oy1, ox0, oxN, pairStore);
-            step<2, (2 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, sTap, i + 2, delta, lane, oy0, oy1, ox0, oxN, pairStore);
-            step<3, (3 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, sTap, i + 3, delta, lane, oy0, oy1, ox0, oxN, pairStore);
-            step<4, (4 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, sTap, i + 4, delta, lane, oy0, oy1, ox0, oxN, pairStore);
-            step<5, (5 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, sTap, i + 5, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<0, (0 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 0, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<1, (1 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 1, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<2, (2 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 2, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<3, (3 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 3, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<4, (4 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 4, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<5, (5 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 5, delta, lane, oy0, oy1, ox0, oxN, pairStore);
         }
     }
 };
 
-template <typename T, int U, int D, int VPH, bool RADIAL>
+template <typename T, int U, int D, int VPH, int RADIAL>
 __global__ void __launch_bounds__(64)
 flrelu_stream_kernel(StreamParams p) {
     Stream<T, U, D, VPH, RADIAL>::run(p);
@@ -464,6 +502,7 @@ static bool stream_supported(int up, int down, int fuW, int fuH, int fdW, int fd
 
 // the streaming kernel evaluates lrelu as max(v, slope * v), valid for 0 <= slope <= 1 (every StyleGAN3 layer)
 static bool stream_params_ok(const sg3_filtered_lrelu_params& q) {
+    if (q.fdH != 0 && ((uintptr_t)q.fd & 15) != 0) return false;  // radial taps are fetched as 16-byte scalar quads
     return q.slope >= 0.f && q.slope <= 1.f && q.xStride[3] == 1 && q.yStride[3] == 1 && !(q.clamp < 0.f);
 }
 
@@ -503,13 +542,14 @@ static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
     const int vph = (((q.py0 - (q.up - 1)) % q.down) + q.down) % q.down;
     dim3 g((unsigned)total), b(64);
 #define SG3_STREAM_LAUNCH(U, V, R) hipLaunchKernelGGL((flrelu_stream_kernel<T, U, 2, V, R>), g, b, 0, st, p)
-    if (q.fdH == 0) {
-        if (q.up == 2) { if (vph == 0) SG3_STREAM_LAUNCH(2, 0, false); else SG3_STREAM_LAUNCH(2, 1, false); }
-        else           { if (vph == 0) SG3_STREAM_LAUNCH(4, 0, false); else SG3_STREAM_LAUNCH(4, 1, false); }
+    const int variant = q.fdH == 0 ? 0 : (q.flip ? 2 : 1);         // separable | radial | radial with flipped taps
+#define SG3_STREAM_LAUNCH_V(U, R) do { if (vph == 0) SG3_STREAM_LAUNCH(U, 0, R); else SG3_STREAM_LAUNCH(U, 1, R); } while (0)
+    if (q.up == 2) {
+        if (variant == 0) SG3_STREAM_LAUNCH_V(2, 0); else if (variant == 1) SG3_STREAM_LAUNCH_V(2, 1); else SG3_STREAM_LAUNCH_V(2, 2);
     } else {
-        if (q.up == 2) { if (vph == 0) SG3_STREAM_LAUNCH(2, 0, true); else SG3_STREAM_LAUNCH(2, 1, true); }
-        else           { if (vph == 0) SG3_STREAM_LAUNCH(4, 0, true); else SG3_STREAM_LAUNCH(4, 1, true); }
+        if (variant == 0) SG3_STREAM_LAUNCH_V(4, 0); else if (variant == 1) SG3_STREAM_LAUNCH_V(4, 1); else SG3_STREAM_LAUNCH_V(4, 2);
     }
+#undef SG3_STREAM_LAUNCH_V
 #undef SG3_STREAM_LAUNCH
     SG3_LAUNCH_CHECK("flrelu_stream_kernel");
     return SG3_OK;

@@ -830,8 +830,8 @@ static int launch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
 
 template <typename T>
 static int dispatch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
-    const int t64 = ceil_div(q.O, 64) * 64, t128 = ceil_div(q.O, 128) * 128;
-    if (t64 < t128) return launch_conv1_f16x3<T, 1, 8, 2, 1>(q, st);              //  64 x (8 rows x 32)
+    // the 128-row tile has twice the MFMAs per LDS fragment read and half the L2 re-reads of the 64-row one
+    if (q.O <= 64) return launch_conv1_f16x3<T, 1, 8, 2, 1>(q, st);               //  64 x (8 rows x 32)
     return launch_conv1_f16x3<T, 2, 4, 2, 2>(q, st);                              // 128 x (8 rows x 32)
 }
 

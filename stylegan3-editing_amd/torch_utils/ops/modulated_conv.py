@@ -70,7 +70,7 @@ def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None):
         else:
             gmode, g = 3, g.expand(n, ci).contiguous()
         gptr = g
-    split = precision == 'f16x3' and (k == 3 or padding == 0) and x_bound is not None and x_bound > 0
+    split = precision == 'f16x3' and (k == 3 or (padding == 0 and co > 4)) and x_bound is not None and x_bound > 0   # ToRGB (O <= 4) is HBM-bound: plain kernel
     prec = abi.SG3_CONV_F16X3 if split else abi.SG3_CONV_FP32
     wn = torch.empty([int(lib.sg3_modconv_packed_floats(co, ci, k, prec))], dtype=torch.float32, device=dev)
     wsq = torch.empty([co, ci], dtype=torch.float32, device=dev)
