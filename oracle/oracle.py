@@ -496,3 +496,108 @@ def backbone_encoder(sd, x, num_layers=50, n_styles=16, return_feats=False):
         codes.append(t @ w.T + sd[f'styles.{j}.linear.bias'][None])
     codes = np.stack(codes, axis=1).astype(np.float32)
     return (codes, feats) if return_feats else codes
+
+
+# ----------------------------------------------------------------------------
+# Callers of the synthesis path: field-of-view expansion, video post-processing, StyleSpace edit sweep.
+# Restated from the reference text; these modules cannot be imported here (imageio / clip / pyrallis are absent),
+# so their parity is pinned by this restatement only.
+
+def make_transform(translate, angle):
+    """utils/common.py:9-19."""
+    m = np.eye(3)
+    s, c = np.sin(angle / 360.0 * np.pi * 2), np.cos(angle / 360.0 * np.pi * 2)
+    m[0][0] = c; m[0][1] = s; m[0][2] = translate[0]
+    m[1][0] = -s; m[1][1] = c; m[1][2] = translate[1]
+    return m
+
+
+def fov_transforms(res, pixels_right, pixels_left, pixels_top, pixels_bottom):
+    """utils/fov_expansion.py:35-84: the nine tile transforms (None where no pixels are requested), already inverted."""
+    def edge(e, n):
+        if n == 0:
+            return None
+        return make_transform({'left': (n / res, 0), 'right': (-n / res, 0), 'top': (0, n / res), 'bottom': (0, -n / res)}[e], 0)
+
+    def corner(cn, nh, nv):
+        if nh == 0 or nv == 0:
+            return None
+        return make_transform({'top_left': (nh / res, nv / res), 'top_right': (-nh / res, nv / res),
+                               'bottom_left': (nh / res, -nv / res), 'bottom_right': (-nh / res, -nv / res)}[cn], 0)
+    ts = [make_transform((0, 0), 0), edge('left', pixels_left), edge('top', pixels_top), edge('right', pixels_right),
+          edge('bottom', pixels_bottom), corner('top_left', pixels_left, pixels_top), corner('top_right', pixels_right, pixels_top),
+          corner('bottom_right', pixels_right, pixels_bottom), corner('bottom_left', pixels_left, pixels_bottom)]
+    return [None if t is None else np.linalg.inv(t) for t in ts]
+
+
+def fov_merge(images, res, pr, pl, pt, pb):
+    """utils/fov_expansion.py:86-108."""
+    out = np.zeros((images[0].shape[0], 3, pt + res + pb, pl + res + pr), np.float32)
+    out[:, :, pt:pt + res, pl:pl + res] = images[0]
+    if pl > 0:
+        out[:, :, pt:pt + res, :pl] = images[1][:, :, :, 0:pl]
+    if pt > 0:
+        out[:, :, :pt, pl:pl + res] = images[2][:, :, 0:pt, :]
+    if pr > 0:
+        out[:, :, pt:pt + res, pl + res:] = images[3][:, :, :, res - pr:]
+    if pb > 0:
+        out[:, :, pt + res:, pl:pl + res] = images[4][:, :, res - pb:, :]
+    if pt > 0 and pl > 0:
+        out[:, :, :pt, :pl] = images[5][:, :, :pt, :pl]
+    if pt > 0 and pr > 0:
+        out[:, :, :pt, res + pl:] = images[6][:, :, :pt, res - pr:]
+    if pb > 0 and pr > 0:
+        out[:, :, res + pt:, res + pl:] = images[7][:, :, res - pb:, res - pr:]
+    if pb > 0 and pl > 0:
+        out[:, :, res + pt:, :pl] = images[8][:, :, res - pb:, :pl]
+    return out
+
+
+def expand_fov(sd, sched, ws, landmark_t, pixels_right=0, pixels_left=0, pixels_top=0, pixels_bottom=0):
+    """utils/fov_expansion.py:13-30: one synthesis pass per tile with transform = landmark_t @ tile transform."""
+    res = sched['img_resolution']
+    images = []
+    for t in fov_transforms(res, pixels_right, pixels_left, pixels_top, pixels_bottom):
+        images.append(None if t is None else synthesis(sd, sched, ws=ws, transform=(landmark_t @ t).astype(np.float32)))
+    return fov_merge(images, res, pixels_right, pixels_left, pixels_top, pixels_bottom)
+
+
+def smooth_ws(ws):
+    """inversion/video/post_processing.py:49-52."""
+    return (ws[2:-2] + 0.75 * ws[3:-1] + 0.75 * ws[1:-3] + 0.25 * ws[:-4] + 0.25 * ws[4:]) / 3
+
+
+def postprocess_latents(result_latents):
+    """inversion/video/post_processing.py:13-19: fine layers averaged over frames, then smoothed."""
+    lat = np.array(result_latents)
+    lat[:, 9:, :] = lat[:, 9:, :].mean(axis=0)
+    return smooth_ws(lat)
+
+
+def styleclip_delta_s(delta_i_c, delta_i, beta, s_std, example_s):
+    """editing/styleclip_global_directions/global_direction.py:7-40."""
+    r_c = delta_i_c @ delta_i
+    delta_s = r_c.copy()
+    delta_s[np.abs(r_c) < beta] = 0
+    peak = np.abs(delta_s).max()
+    if peak > 0:
+        delta_s = delta_s / peak
+    out, start = {}, 0
+    for key in example_s:
+        n = example_s[key].shape[1]
+        out[key] = (delta_s[start:start + n] * s_std[key])[None]
+        start += n
+    return out
+
+
+def styleclip_sweep(sd, sched, latent, delta_i_c, delta_i, s_std, alphas, betas, transform=None):
+    """editing/styleclip_global_directions/edit.py:124-168: W2S, then one batch-1 synthesis per (beta, alpha)."""
+    s = w2s(sd, sched, latent[None])
+    base = {c: s[c][0][None] for c in s}
+    images = []
+    for beta in betas:
+        d = styleclip_delta_s(delta_i_c, delta_i, beta, s_std, base)
+        for alpha in alphas:
+            edited = {c: (base[c] + np.float32(alpha) * d[c]).astype(np.float32) for c in base}
+            images.append(synthesis(sd, sched, all_s=edited, transform=transform))
+    return np.concatenate(images)
