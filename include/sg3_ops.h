@@ -223,11 +223,14 @@ enum {
     SG3_CONV_F16X3 = 1,  /* operands split x = hi + lo into two fp16 halves; hi*hi + hi*lo + lo*hi on
                           * v_mfma_f32_32x32x16_f16 with fp32 accumulation: every retained product is exact, the
                           * dropped lo*lo term is 2^-22 relative (fp32-equivalent), 5.3x the fp32 MFMA rate.
-                          * 3x3 kernels only; needs a bound on |x| (xBound) to keep the halves in fp16 range */
+                          * needs a bound on |x| (xBound) to keep the halves in fp16 range */
+    SG3_CONV_F16   = 2,  /* operands rounded to fp16 once, one v_mfma_f32_32x32x16_f16 per K step, fp32 accumulation:
+                          * the arithmetic of the reference's fp16 layers (networks_stylegan3.py:59-62 with fp16 x and
+                          * w.to(x.dtype)); same packing, xBound and power-of-two rescale as SG3_CONV_F16X3 */
 };
 
 /* number of floats (4-byte units) of the packed weight buffer for an [O,I,k,k] weight
- * (fp32: [O][ceil(I/KC)][k*k][KC] floats; f16x3: [O][ceil(I/16)][k*k][hi|lo][16] halfs; zero padded). */
+ * (fp32: [O][ceil(I/KC)][k*k][KC] floats; f16x3 / f16: [O][chunks][k*k][hi|lo][16] halfs, chunks = ceil(I/16), rounded up to even for k = 1; zero padded). */
 SG3_API int64_t sg3_modconv_packed_floats(int O, int I, int k, int precision);
 
 /* Demodulation coefficients and input scales
@@ -252,7 +255,7 @@ typedef struct sg3_modconv_prep_params {
     int32_t        inputGainMode;
     int32_t        N, I, O, k;
     int32_t        demodulate;
-    int32_t        precision;  /* SG3_CONV_FP32 | SG3_CONV_F16X3 */
+    int32_t        precision;  /* SG3_CONV_FP32 | SG3_CONV_F16X3 | SG3_CONV_F16 */
     float          xBound;     /* f16x3 only: max |x| the conv will see (> 0).  sIn is scaled by a power of two per
                                 * sample so that |x * sIn| stays below 2^15, and dcoef (required, also without
                                 * demodulation) carries the inverse */

@@ -216,6 +216,10 @@ template <> struct bufld<_Float16> {
 
 // x = hi + lo with hi = the top 11 significand bits of x (exactly representable in fp16 for normal-range values) and
 // lo = fp16(x - hi); two values per call, packed for the MFMA operand registers
+__device__ __forceinline__ v2h round2(float x0, float x1) {          // plain fp16 form: round to nearest even
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    return __builtin_convertvector((f2){x0, x1}, v2h);
+}
 __device__ __forceinline__ void split2(float x0, float x1, v2h& hi, v2h& lo) {
     const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x0) & 0xffffe000u);
     const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x1) & 0xffffe000u);
@@ -223,10 +227,13 @@ __device__ __forceinline__ void split2(float x0, float x1, v2h& hi, v2h& lo) {
     lo = __builtin_bit_cast(v2h, __builtin_amdgcn_cvt_pkrtz(x0 - h0, x1 - h1));
 }
 
-template <typename T, int WM, int WN, int TM, int TN>
+// SPLIT = false is the plain fp16 form (SG3_CONV_F16): operands rounded to fp16 once, ONE MFMA per K step -- the
+// arithmetic of the reference's fp16 layers (fp16 cuDNN convolution with fp32 accumulation).
+template <typename T, int WM, int WN, int TM, int TN, bool SPLIT>
 __global__ void __launch_bounds__(256, (TM * TN <= 4) ? 2 : 1)      // two workgroups per CU whenever the accumulators allow
 modconv_f16x3_kernel(ConvParams p) {
     constexpr int KS = 3, TAPS = 9, KC = 16;
+    constexpr int NPART = SPLIT ? 2 : 1;               // B planes per channel half: hi | lo
     constexpr int BM = WM * TM * 32;
     constexpr int ROWS = WN * TN;
     constexpr int PH = ROWS + KS - 1, PW = 32 + KS - 1;
@@ -328,10 +335,14 @@ modconv_f16x3_kernel(ConvParams p) {
             for (int hf = 0; hf < 2; hf++) {
                 v2h h[4], l[4];
 #pragma unroll
-                for (int c = 0; c < 4; c++) split2(rb[q][hf][2 * c], rb[q][hf][2 * c + 1], h[c], l[c]);
-                _Float16* dst = sB + (hf * 2) * BPLANE + bL[q];
+                for (int c = 0; c < 4; c++) {
+                    if (SPLIT) split2(rb[q][hf][2 * c], rb[q][hf][2 * c + 1], h[c], l[c]);
+                    else h[c] = round2(rb[q][hf][2 * c], rb[q][hf][2 * c + 1]);
+                }
+                _Float16* dst = sB + (hf * NPART) * BPLANE + bL[q];
                 *reinterpret_cast<v8h*>(dst) = __builtin_shufflevector(__builtin_shufflevector(h[0], h[1], 0, 1, 2, 3), __builtin_shufflevector(h[2], h[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
-                *reinterpret_cast<v8h*>(dst + BPLANE) = __builtin_shufflevector(__builtin_shufflevector(l[0], l[1], 0, 1, 2, 3), __builtin_shufflevector(l[2], l[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
+                if (SPLIT)
+                    *reinterpret_cast<v8h*>(dst + BPLANE) = __builtin_shufflevector(__builtin_shufflevector(l[0], l[1], 0, 1, 2, 3), __builtin_shufflevector(l[2], l[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
             }
         }
     };
@@ -344,13 +355,13 @@ modconv_f16x3_kernel(ConvParams p) {
         for (int a = 0; a < TM; a++) {
             const _Float16* src = sA + ((wm * TM + a) * 32 + li) * AS + tap * 32 + lh * 8;
             f.ah[a] = *reinterpret_cast<const v8h*>(src);
-            f.al[a] = *reinterpret_cast<const v8h*>(src + 16);
+            if (SPLIT) f.al[a] = *reinterpret_cast<const v8h*>(src + 16);
         }
 #pragma unroll
         for (int b = 0; b < TN; b++) {
-            const _Float16* src = sB + (lh * 2) * BPLANE + ((wn * TN + b + ky) * PW + li + kx) * 8;
+            const _Float16* src = sB + (lh * NPART) * BPLANE + ((wn * TN + b + ky) * PW + li + kx) * 8;
             f.bh[b] = *reinterpret_cast<const v8h*>(src);
-            f.bl[b] = *reinterpret_cast<const v8h*>(src + BPLANE);
+            if (SPLIT) f.bl[b] = *reinterpret_cast<const v8h*>(src + BPLANE);
         }
     };
     auto mfma_tap = [&](const Frags& f) {
@@ -358,8 +369,10 @@ modconv_f16x3_kernel(ConvParams p) {
         for (int a = 0; a < TM; a++)
 #pragma unroll
             for (int b = 0; b < TN; b++) {
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[a], f.bh[b], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bl[b], acc[a][b], 0, 0, 0);
+                if (SPLIT) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[a], f.bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bl[b], acc[a][b], 0, 0, 0);
+                }
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bh[b], acc[a][b], 0, 0, 0);
             }
     };
@@ -411,10 +424,11 @@ modconv_f16x3_kernel(ConvParams p) {
 // larger along M (128 x 256 pixels, eight waves, wave tile 64 x 64) to keep the L2 -> LDS stream at ~44 FLOP/B, two
 // 16-channel K steps are staged per barrier, and the LDS image is double-buffered: one barrier per 32 input channels.
 // LDS per buffer: A rows of (hi16|lo16) x 2 halfs + 8 halfs of padding; B as planes [k-step][channel-half][hi|lo][pixel][8].
-template <typename T, int WM, int WN, int TM, int TN>
+template <typename T, int WM, int WN, int TM, int TN, bool SPLIT>
 __global__ void __launch_bounds__(512)
 modconv1_f16x3_kernel(ConvParams p) {
     constexpr int KSUB = 2, KC = 16 * KSUB;
+    constexpr int NPART = SPLIT ? 2 : 1;
     constexpr int BM = WM * TM * 32;
     constexpr int ROWS = WN * TN;
     constexpr int NPIX = ROWS * 32;
@@ -423,7 +437,7 @@ modconv1_f16x3_kernel(ConvParams p) {
     constexpr int A_VEC = BM * AROW_V;
     constexpr int A_PER = (A_VEC + 511) / 512;
     constexpr int BPLANE = NPIX * 8;                   // halfs per (k-step, channel-half, part) plane
-    constexpr int BUF = BM * AS + KSUB * 4 * BPLANE;   // halfs per LDS buffer
+    constexpr int BUF = BM * AS + KSUB * 2 * NPART * BPLANE;   // halfs per LDS buffer
     static_assert(WM * WN == 8, "8 waves per workgroup");
     static_assert(NPIX == 256, "one patch pixel per thread pair");
 
@@ -502,10 +516,14 @@ modconv1_f16x3_kernel(ConvParams p) {
         for (int sub = 0; sub < KSUB; sub++) {
             v2h h[4], l[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) split2(rb[sub][2 * c], rb[sub][2 * c + 1], h[c], l[c]);
-            _Float16* dst = sB + ((sub * 2 + kh) * 2) * BPLANE + e * 8;
+            for (int c = 0; c < 4; c++) {
+                if (SPLIT) split2(rb[sub][2 * c], rb[sub][2 * c + 1], h[c], l[c]);
+                else h[c] = round2(rb[sub][2 * c], rb[sub][2 * c + 1]);
+            }
+            _Float16* dst = sB + ((sub * 2 + kh) * NPART) * BPLANE + e * 8;
             *reinterpret_cast<v8h*>(dst) = __builtin_shufflevector(__builtin_shufflevector(h[0], h[1], 0, 1, 2, 3), __builtin_shufflevector(h[2], h[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
-            *reinterpret_cast<v8h*>(dst + BPLANE) = __builtin_shufflevector(__builtin_shufflevector(l[0], l[1], 0, 1, 2, 3), __builtin_shufflevector(l[2], l[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
+            if (SPLIT)
+                *reinterpret_cast<v8h*>(dst + BPLANE) = __builtin_shufflevector(__builtin_shufflevector(l[0], l[1], 0, 1, 2, 3), __builtin_shufflevector(l[2], l[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
         }
     };
     struct Frags { v8h ah[TM], al[TM], bh[TN], bl[TN]; };
@@ -516,13 +534,13 @@ modconv1_f16x3_kernel(ConvParams p) {
         for (int a = 0; a < TM; a++) {
             const _Float16* src = sA + ((wm * TM + a) * 32 + li) * AS + sub * 32 + lh * 8;
             f.ah[a] = *reinterpret_cast<const v8h*>(src);
-            f.al[a] = *reinterpret_cast<const v8h*>(src + 16);
+            if (SPLIT) f.al[a] = *reinterpret_cast<const v8h*>(src + 16);
         }
 #pragma unroll
         for (int b = 0; b < TN; b++) {
-            const _Float16* src = sB + ((sub * 2 + lh) * 2) * BPLANE + ((wn * TN + b) * 32 + li) * 8;
+            const _Float16* src = sB + ((sub * 2 + lh) * NPART) * BPLANE + ((wn * TN + b) * 32 + li) * 8;
             f.bh[b] = *reinterpret_cast<const v8h*>(src);
-            f.bl[b] = *reinterpret_cast<const v8h*>(src + BPLANE);
+            if (SPLIT) f.bl[b] = *reinterpret_cast<const v8h*>(src + BPLANE);
         }
     };
     auto mfma_step = [&](const Frags& f) {
@@ -530,8 +548,10 @@ modconv1_f16x3_kernel(ConvParams p) {
         for (int a = 0; a < TM; a++)
 #pragma unroll
             for (int b = 0; b < TN; b++) {
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[a], f.bh[b], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bl[b], acc[a][b], 0, 0, 0);
+                if (SPLIT) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[a], f.bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bl[b], acc[a][b], 0, 0, 0);
+                }
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bh[b], acc[a][b], 0, 0, 0);
             }
     };
@@ -659,7 +679,7 @@ modconv_prep_w_kernel(sg3_modconv_prep_params p, int kc, int nch) {
         for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
         scale = rsqrtf(red[0] / (float)len);
     }
-    if (p.precision == SG3_CONV_F16X3) {
+    if (p.precision != SG3_CONV_FP32) {
         // [o][chunk][tap][hi|lo][16] halfs
         _Float16* dsth = reinterpret_cast<_Float16*>(p.wPacked) + (size_t)o * nch * taps * 32;
         for (int j = threadIdx.x; j < nch * taps * 16; j += 256) {
@@ -713,9 +733,9 @@ modconv_prep_s_kernel(sg3_modconv_prep_params p) {
         s2[p.I + i] = v;
         smax = fmaxf(smax, fabsf(v));
     }
-    // f16x3: per-sample power-of-two scale keeping |x * sIn| below 2^15
+    // f16x3 / f16: per-sample power-of-two scale keeping |x * sIn| below 2^15
     float down = 1.f, up = 1.f;
-    if (p.precision == SG3_CONV_F16X3) {
+    if (p.precision != SG3_CONV_FP32) {
         __syncthreads();
         red[threadIdx.x] = smax;
         __syncthreads();
@@ -734,7 +754,7 @@ modconv_prep_s_kernel(sg3_modconv_prep_params p) {
             for (int i = 0; i < p.I; i++) s += wq[i] * s2[i];
             p.dcoef[(size_t)n * p.O + o] = rsqrtf(s + 1e-8f) * up;
         }
-    } else if (p.precision == SG3_CONV_F16X3) {
+    } else if (p.precision != SG3_CONV_FP32) {
         for (int o = threadIdx.x; o < p.O; o += 256) p.dcoef[(size_t)n * p.O + o] = up;
     }
 }
@@ -775,11 +795,11 @@ static int dispatch_conv(const sg3_modconv_params& q, hipStream_t st) {
     }
 }
 
-template <typename T, int WM, int WN, int TM, int TN>
+template <typename T, int WM, int WN, int TM, int TN, bool SPLIT>
 static int launch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     constexpr int BM = WM * TM * 32, ROWS = WN * TN;
     constexpr int PH = ROWS + 2, PW = 34;
-    constexpr size_t ldsBytes = ((size_t)BM * (9 * 32 + 8) + 4 * (size_t)PH * PW * 8) * sizeof(_Float16);
+    constexpr size_t ldsBytes = ((size_t)BM * (9 * 32 + 8) + (SPLIT ? 4 : 2) * (size_t)PH * PW * 8) * sizeof(_Float16);
     ConvParams p;
     p.x = q.x; p.wp = q.wPacked; p.sIn = q.sIn; p.dcoef = q.dcoef; p.out = q.out;
     p.N = q.N; p.I = q.I; p.O = q.O; p.H = q.H; p.W = q.W; p.pad = q.pad;
@@ -789,7 +809,7 @@ static int launch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     const long long total = (long long)p.xTiles * p.yTiles * p.mTiles * q.N;
     if (total > 0x7fffffffLL) { set_error("modulated_conv2d: grid too large"); return SG3_BAD_ARG; }
     p.totalBlocks = (int)total;
-    auto kern = modconv_f16x3_kernel<T, WM, WN, TM, TN>;
+    auto kern = modconv_f16x3_kernel<T, WM, WN, TM, TN, SPLIT>;
     if (ldsBytes > 64 * 1024)
         SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), ldsBytes, st, p);
@@ -797,20 +817,20 @@ static int launch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     return SG3_OK;
 }
 
-template <typename T>
+template <typename T, bool SPLIT>
 static int dispatch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     const int O = q.O;
     // two workgroups per CU (<= 80 KB LDS each) so one stages while the other runs its MFMAs
-    if (O <= 32) return launch_conv_f16x3<T, 1, 4, 1, 2>(q, st);                    //  32 x (8 rows x 32)
+    if (O <= 32) return launch_conv_f16x3<T, 1, 4, 1, 2, SPLIT>(q, st);             //  32 x (8 rows x 32)
     const int t64 = ceil_div(O, 64) * 64, t96 = ceil_div(O, 96) * 96;
-    if (t96 < t64) return launch_conv_f16x3<T, 1, 4, 3, 2>(q, st);                  //  96 x (8 rows x 32)
-    return launch_conv_f16x3<T, 1, 4, 2, 2>(q, st);                                 //  64 x (8 rows x 32)
+    if (t96 < t64) return launch_conv_f16x3<T, 1, 4, 3, 2, SPLIT>(q, st);           //  96 x (8 rows x 32)
+    return launch_conv_f16x3<T, 1, 4, 2, 2, SPLIT>(q, st);                          //  64 x (8 rows x 32)
 }
 
-template <typename T, int WM, int WN, int TM, int TN>
+template <typename T, int WM, int WN, int TM, int TN, bool SPLIT>
 static int launch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     constexpr int BM = WM * TM * 32, ROWS = WN * TN;
-    constexpr size_t ldsBytes = 2 * ((size_t)BM * (2 * 32 + 8) + 8 * (size_t)ROWS * 32 * 8) * sizeof(_Float16);
+    constexpr size_t ldsBytes = 2 * ((size_t)BM * (2 * 32 + 8) + (SPLIT ? 8 : 4) * (size_t)ROWS * 32 * 8) * sizeof(_Float16);
     ConvParams p;
     p.x = q.x; p.wp = q.wPacked; p.sIn = q.sIn; p.dcoef = q.dcoef; p.out = q.out;
     p.N = q.N; p.I = q.I; p.O = q.O; p.H = q.H; p.W = q.W; p.pad = 0;
@@ -820,7 +840,7 @@ static int launch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     const long long total = (long long)p.xTiles * p.yTiles * p.mTiles * q.N;
     if (total > 0x7fffffffLL) { set_error("modulated_conv2d: grid too large"); return SG3_BAD_ARG; }
     p.totalBlocks = (int)total;
-    auto kern = modconv1_f16x3_kernel<T, WM, WN, TM, TN>;
+    auto kern = modconv1_f16x3_kernel<T, WM, WN, TM, TN, SPLIT>;
     if (ldsBytes > 64 * 1024)
         SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), ldsBytes, st, p);
@@ -828,11 +848,11 @@ static int launch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     return SG3_OK;
 }
 
-template <typename T>
+template <typename T, bool SPLIT>
 static int dispatch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     // the 128-row tile has twice the MFMAs per LDS fragment read and half the L2 re-reads of the 64-row one
-    if (q.O <= 64) return launch_conv1_f16x3<T, 1, 8, 2, 1>(q, st);               //  64 x (8 rows x 32)
-    return launch_conv1_f16x3<T, 2, 4, 2, 2>(q, st);                              // 128 x (8 rows x 32)
+    if (q.O <= 64) return launch_conv1_f16x3<T, 1, 8, 2, 1, SPLIT>(q, st);        //  64 x (8 rows x 32)
+    return launch_conv1_f16x3<T, 2, 4, 2, 2, SPLIT>(q, st);                       // 128 x (8 rows x 32)
 }
 
 } // namespace sg3
@@ -841,7 +861,7 @@ extern "C" {
 
 int64_t sg3_modconv_packed_floats(int O, int I, int k, int precision) {
     if (O <= 0 || I <= 0 || (k != 1 && k != 3)) return 0;
-    if (precision == SG3_CONV_F16X3) {
+    if (precision == SG3_CONV_F16X3 || precision == SG3_CONV_F16) {
         return (int64_t)O * sg3::f16x3_chunks(I, k) * (k * k) * 16;   // 32 halfs = 16 floats per (chunk, tap)
     }
     const int kc = sg3::packed_kc(k);
@@ -857,13 +877,13 @@ int sg3_modulated_conv2d_prep(const sg3_modconv_prep_params* p, void* stream) {
     SG3_REQUIRE(p->inputGainMode >= 0 && p->inputGainMode <= 3, "modulated_conv2d_prep: bad inputGainMode");
     SG3_REQUIRE(p->inputGainMode == 0 || p->inputGain, "modulated_conv2d_prep: inputGain missing");
     SG3_REQUIRE((size_t)p->I * 2 * sizeof(float) <= 48 * 1024, "modulated_conv2d_prep: too many input channels");
-    SG3_REQUIRE(p->precision == SG3_CONV_FP32 || p->precision == SG3_CONV_F16X3, "modulated_conv2d_prep: bad precision");
-    if (p->precision == SG3_CONV_F16X3) {
+    SG3_REQUIRE(p->precision == SG3_CONV_FP32 || p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16, "modulated_conv2d_prep: bad precision");
+    if (p->precision != SG3_CONV_FP32) {
         SG3_REQUIRE(p->xBound > 0.f && p->dcoef, "modulated_conv2d_prep: f16x3 needs xBound > 0 and a dcoef buffer");
     }
     hipStream_t st = (hipStream_t)stream;
     const int kc = packed_kc(p->k);
-    const int nch = p->precision == SG3_CONV_F16X3 ? f16x3_chunks(p->I, p->k) : ceil_div(p->I, kc);
+    const int nch = p->precision != SG3_CONV_FP32 ? f16x3_chunks(p->I, p->k) : ceil_div(p->I, kc);
     hipLaunchKernelGGL(modconv_prep_w_kernel, dim3(p->O), dim3(256), 0, st, *p, kc, nch);
     SG3_LAUNCH_CHECK("modconv_prep_w_kernel");
     hipLaunchKernelGGL(modconv_prep_s_kernel, dim3(p->N), dim3(256), (size_t)p->I * 2 * sizeof(float), st, *p);
@@ -880,12 +900,16 @@ int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream) {
     SG3_REQUIRE(p->H + 2 * p->pad - p->k + 1 > 0 && p->W + 2 * p->pad - p->k + 1 > 0, "modulated_conv2d: empty output");
     SG3_REQUIRE(p->dtype == SG3_F32 || p->dtype == SG3_F16, "modulated_conv2d: unsupported dtype");
     hipStream_t st = (hipStream_t)stream;
-    if (p->precision == SG3_CONV_F16X3) {
+    if (p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16) {
         SG3_REQUIRE(p->dcoef, "modulated_conv2d: f16x3 needs dcoef");
         SG3_REQUIRE(p->k == 3 || p->pad == 0, "modulated_conv2d: f16x3 1x1 kernels take no padding");
         SG3_REQUIRE((int64_t)p->I * p->H * p->W * 4 < (int64_t)1 << 31, "modulated_conv2d: f16x3 needs a sample below 2 GiB (32-bit offsets)");
-        if (p->k == 1) return p->dtype == SG3_F32 ? dispatch_conv1_f16x3<float>(*p, st) : dispatch_conv1_f16x3<_Float16>(*p, st);
-        return p->dtype == SG3_F32 ? dispatch_conv_f16x3<float>(*p, st) : dispatch_conv_f16x3<_Float16>(*p, st);
+        if (p->precision == SG3_CONV_F16) {
+            if (p->k == 1) return p->dtype == SG3_F32 ? dispatch_conv1_f16x3<float, false>(*p, st) : dispatch_conv1_f16x3<_Float16, false>(*p, st);
+            return p->dtype == SG3_F32 ? dispatch_conv_f16x3<float, false>(*p, st) : dispatch_conv_f16x3<_Float16, false>(*p, st);
+        }
+        if (p->k == 1) return p->dtype == SG3_F32 ? dispatch_conv1_f16x3<float, true>(*p, st) : dispatch_conv1_f16x3<_Float16, true>(*p, st);
+        return p->dtype == SG3_F32 ? dispatch_conv_f16x3<float, true>(*p, st) : dispatch_conv_f16x3<_Float16, true>(*p, st);
     }
     SG3_REQUIRE(p->precision == SG3_CONV_FP32, "modulated_conv2d: bad precision");
     if (p->k == 1 && p->pad == 0 && p->O <= 4 && (size_t)p->I * 4 * sizeof(float) <= 48 * 1024)

@@ -27,7 +27,8 @@ from .. import misc
 #   'f16x3' : fp16 hi/lo operand split, three fp16 MFMAs per K step, fp32 accumulation (fp32-equivalent: every
 #             retained product is exact, the dropped lo*lo term is 2^-22 relative) at 5.3x the fp32 MFMA rate;
 #   'fp32'  : v_mfma_f32_32x32x2_f32, exact fp32 products.
-# Calls without a bound always use 'fp32'.
+# Calls without a bound always use 'fp32'.  fp16 tensors (the reference's mixed-precision layers) take the plain fp16
+# form: operands rounded to fp16 once, one MFMA per K step, fp32 accumulation -- what an fp16 cuDNN convolution does.
 precision = 'f16x3'
 
 
@@ -70,8 +71,10 @@ def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None):
         else:
             gmode, g = 3, g.expand(n, ci).contiguous()
         gptr = g
+    if x.dtype == torch.float16 and x_bound is None:
+        x_bound = 65504.0                                   # the dtype's own range
     split = precision == 'f16x3' and (k == 3 or (padding == 0 and co > 4)) and x_bound is not None and x_bound > 0   # ToRGB (O <= 4) is HBM-bound: plain kernel
-    prec = abi.SG3_CONV_F16X3 if split else abi.SG3_CONV_FP32
+    prec = (abi.SG3_CONV_F16 if x.dtype == torch.float16 else abi.SG3_CONV_F16X3) if split else abi.SG3_CONV_FP32
     wn = torch.empty([int(lib.sg3_modconv_packed_floats(co, ci, k, prec))], dtype=torch.float32, device=dev)
     wsq = torch.empty([co, ci], dtype=torch.float32, device=dev)
     s_in = torch.empty([n, ci], dtype=torch.float32, device=dev)

@@ -89,3 +89,25 @@ def test_synthesis_properties_full_size():
         c = G.synthesis(ws, noise_mode='const', force_fp32=True)
     assert torch.equal(a, c)
     assert maxabs(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5
+
+
+def test_mixed_precision_default_path():
+    """The reference's default execution on a GPU: layers flagged use_fp16 run with fp16 activations (fp16 MFMA
+    convolution with fp32 accumulation, fp16 I/O in filtered_lrelu with fp32 arithmetic).  No golden exists (the
+    reference's CPU path is always fp32), so the fp32 image is the yardstick: fp16 rounding of O(1..256)
+    activations through ten layers."""
+    G = build_product_generator('T1024', device=DEV)
+    assert [getattr(G.synthesis, n).use_fp16 for n in G.synthesis.layer_names] == [False] * 5 + [True] * 10
+    ws = T(synth_ws(1, G.num_ws, G.w_dim, seed=1))
+    feats = []
+    hooks = [getattr(G.synthesis, n).register_forward_hook(lambda m, i, o: feats.append(o.dtype)) for n in G.synthesis.layer_names]
+    with torch.no_grad():
+        a = G.synthesis(ws, noise_mode='const')
+        for h in hooks:
+            h.remove()
+        b = G.synthesis(ws, noise_mode='const', force_fp32=True)
+    assert feats == [torch.float32] * 5 + [torch.float16] * 10 and a.dtype == torch.float32
+    assert bool(torch.isfinite(a).all())
+    d = (a - b).abs()
+    print('mixed vs fp32: max', float(d.max()), 'mean', float(d.mean()))
+    assert float(d.max()) <= 5e-2 and float(d.mean()) <= 3e-3

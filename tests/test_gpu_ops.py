@@ -303,6 +303,27 @@ def test_modulated_conv2d_split_precision_1x1(n, ci, co, h):
     assert yh.dtype == torch.float16 and maxabs(yh.float().cpu().numpy(), refh) <= 2e-3 * max(1.0, float(np.abs(refh).max()))
 
 
+@pytest.mark.parametrize('n,ci,co,h,k', [(2, 203, 128, 37, 3), (1, 81, 51, 50, 3), (2, 645, 406, 20, 1), (1, 64, 64, 33, 1)])
+def test_modulated_conv2d_fp16_form(n, ci, co, h, k):
+    """fp16 tensors take the single-MFMA fp16 form (SG3_CONV_F16): equal to the fp64 result for operands rounded to
+    fp16 up to fp16 rounding of (x * s), of the weights and of the output."""
+    from oracle import oracle as O
+    from torch_utils.ops import modulated_conv as mc
+    x = np.clip(rand(91, n, ci, h, h + 3) * 20, -256, 256).astype(np.float16); w = rand(92, co, ci, k, k); s = rand(93, n, ci) + 1
+    ref = O.modulated_conv2d(x.astype(np.float64), w.astype(np.float64), s.astype(np.float64), True, k - 1, 0.8)
+    y = mc.modulated_conv2d(T(x), T(w), T(s), demodulate=True, padding=k - 1, input_gain=torch.tensor(0.8, device=DEV))
+    assert y.dtype == torch.float16 and tuple(y.shape) == ref.shape
+    err = np.abs(y.float().cpu().numpy() - ref)
+    scale = float(np.abs(ref).max())
+    assert err.max() <= 4e-3 * scale and err.mean() <= 4e-4 * scale
+    mc.precision = 'fp32'
+    try:
+        y32 = mc.modulated_conv2d(T(x), T(w), T(s), demodulate=True, padding=k - 1, input_gain=torch.tensor(0.8, device=DEV))
+    finally:
+        mc.precision = 'f16x3'
+    assert maxabs(y32.float().cpu().numpy(), ref) <= 1e-3 * scale                   # exact products: only the fp16 output rounding
+
+
 def test_modulated_conv2d_fp16_and_grad():
     from oracle import oracle as O
     from models.stylegan3.networks_stylegan3 import modulated_conv2d
