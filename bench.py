@@ -149,6 +149,33 @@ def bench_inversion(G, device, rank, world, frames_per_gpu=16, restyle_steps=5, 
                          'all-gather of [F,16,512] latents; synthetic weights')
 
 
+def bench_extras(G, ws, device, steps=5):
+    """Secondary single-GPU measurements (eager launches, not the headline): the reference's default mixed-precision
+    execution of the same workload, and config R (1x1 convolutions, radial down filters) at 1024 and 512."""
+    from synth_weights import synth_ws
+
+    def run(gen, w, **kw):
+        with torch.no_grad():
+            for _ in range(2):
+                gen.synthesis(w, noise_mode='const', **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                gen.synthesis(w, noise_mode='const', **kw)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        return {'imgs_per_s': int(w.shape[0]) / dt, 'ms_per_step': dt * 1e3, 'batch': int(w.shape[0])}
+
+    out = {'T1024_mixed_fp16': run(G, ws)}
+    for cfg, batch in (('R1024', 4), ('R512', 8)):
+        gen = build_generator(cfg, device)
+        w = torch.from_numpy(synth_ws(batch, gen.num_ws, gen.w_dim, seed=1)).to(device)
+        out[cfg + '_fp32'] = run(gen, w, force_fp32=True)
+        del gen
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -159,6 +186,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-inversion', action='store_true', help='skip the secondary ReStyle inversion measurement')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a captured hipGraph')
+    ap.add_argument('--no-extras', action='store_true', help='skip the secondary mixed-precision / config-R measurements')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -234,6 +262,9 @@ def main():
     inversion = None
     if not args.no_inversion and args.config == 'T1024':
         inversion = bench_inversion(G, device, rank, world)
+    extras = None
+    if not args.no_extras and world == 1 and args.config == 'T1024':
+        extras = bench_extras(G, ws, device)
 
     if rank == 0:
         total_bytes, _ = flrelu_algorithmic_bytes(G, args.batch)
@@ -266,6 +297,7 @@ def main():
                         'peak_fp32_mfma_tflops': 157.3, 'kernel_ms_per_step': conv_ms},
         }
         out['inversion'] = inversion
+        out['extras'] = extras
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.config)
         else:

@@ -1,0 +1,92 @@
+"""Pivotal tuning (PTI) of the generator around one inverted image (reference inversion/scripts/run_pti_images.py:104-177).
+
+The generator weights (everything in `synthesis` except the Fourier-feature input's three parameters) are tuned with
+Adam so that synthesis(latent) reproduces the target:  loss = l2_lambda * MSE + lpips_lambda * LPIPS.  The forward is
+the fp32 synthesis path on the HIP kernels; the backward runs through the ops' autograd functions (filtered_lrelu:
+sign-tensor adjoint; modulated conv: gradients of the reference formulation).
+
+LPIPS needs pretrained AlexNet weights that are not part of this package: pass `lpips_loss` (a callable
+(generated, real) -> scalar tensor) or set opts.lpips_lambda = 0.  Image decoding / the side-by-side JPEG dumps of the
+reference are I/O outside the hot path: targets are tensors in [-1, 1].
+"""
+import types
+
+import numpy as np
+import torch
+from torch import nn
+
+
+def default_opts(**overrides):
+    """Defaults of the reference RunConfig (:25-60) that the optimisation itself reads."""
+    o = types.SimpleNamespace(device='cuda', steps=350, learning_rate=3e-4, lpips_lambda=1.0, l2_lambda=1.0,
+                              lpips_threshold=0.06, batch_size=2, num_workers=0, save_interval=None,
+                              model_save_interval=None, save_final_model=False, output_path=None)
+    for k, v in overrides.items():
+        setattr(o, k, v)
+    return o
+
+
+def as_image_batch(t, device):
+    t = torch.as_tensor(np.asarray(t) if not isinstance(t, torch.Tensor) else t).to(device).float()
+    return t.unsqueeze(0) if t.ndim == 3 else t
+
+
+class PTI:
+
+    def __init__(self, opts, lpips_loss=None):
+        self.opts = opts
+        self.device = opts.device
+        self.mse_loss = nn.MSELoss().to(self.device).eval()
+        self.lpips_loss = lpips_loss
+        if opts.lpips_lambda > 0 and lpips_loss is None:
+            raise RuntimeError('PTI: opts.lpips_lambda > 0 needs an lpips_loss callable (the pretrained LPIPS network is external)')
+        self.history = []                                 # (step, loss, lpips, l2) floats of the last optimize_model call
+
+    def get_optimizer(self, generator):
+        # do not alter the fourier features
+        params = list(generator.synthesis.parameters())[3:]
+        return torch.optim.Adam(params, lr=self.opts.learning_rate)
+
+    def optimize_model(self, generator, codes, target_images, landmarks_transforms=None, image_name=None):
+        optimizer = self.get_optimizer(generator)
+        latents = torch.from_numpy(np.asarray(codes)).to(self.device).unsqueeze(0)
+        targets = as_image_batch(target_images, self.device)
+        outputs = None
+        self.history = []
+        if landmarks_transforms is not None:
+            generator.synthesis.input.transform = torch.from_numpy(np.asarray(landmarks_transforms)).to(self.device).float()
+        for step in range(self.opts.steps):
+            outputs = generator.synthesis(latents, noise_mode='const', force_fp32=True)
+            loss, lpips_loss, l2_loss_val = self.calc_loss(outputs, targets)
+            if lpips_loss is not None and lpips_loss < self.opts.lpips_threshold:
+                break
+            self.history.append((step, float(loss.detach()), None if lpips_loss is None else float(lpips_loss.detach()),
+                                 None if l2_loss_val is None else float(l2_loss_val.detach())))
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+        if self.opts.save_final_model and self.opts.output_path is not None:
+            name = (image_name or 'image').split('.')[0]
+            torch.save(generator.state_dict(), self.opts.output_path / f'final_pti_model_{name}.pt')
+        return outputs
+
+    def calc_loss(self, generated_images, real_images):
+        loss = 0.0
+        loss_lpips = None
+        l2_loss_val = None
+        if self.opts.l2_lambda > 0:
+            l2_loss_val = self.mse_loss(generated_images, real_images)
+            loss += l2_loss_val * self.opts.l2_lambda
+        if self.opts.lpips_lambda > 0:
+            loss_lpips = self.lpips_loss(generated_images, real_images)
+            loss += loss_lpips * self.opts.lpips_lambda
+        return loss, loss_lpips, l2_loss_val
+
+    @staticmethod
+    def get_description(step, loss, lpips_loss, l2_loss_val):
+        desc = f'Step: {step} - Loss: {loss.item():.4f}'
+        if lpips_loss is not None:
+            desc += f', LPIPS: {lpips_loss.item():.4f}'
+        if l2_loss_val is not None:
+            desc += f', L2: {l2_loss_val.item():.4f}'
+        return desc

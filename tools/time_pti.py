@@ -1,0 +1,26 @@
+"""Time PTI steps (forward + backward + Adam) for a named config, e.g.  python tools/time_pti.py T1024 --batch 1"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, 'stylegan3-editing_amd'), os.path.join(ROOT, 'tests'), ROOT):
+    sys.path.insert(0, p)
+import torch, warnings  # noqa: E402
+from helpers import build_product_generator  # noqa: E402
+from synth_weights import synth_ws  # noqa: E402
+ap = argparse.ArgumentParser(); ap.add_argument('cfg'); ap.add_argument('--batch', type=int, default=1); ap.add_argument('--iters', type=int, default=3)
+a = ap.parse_args()
+warnings.simplefilter('ignore')
+G = build_product_generator(a.cfg, device='cuda:0'); G.requires_grad_(True)
+opt = torch.optim.Adam(list(G.synthesis.parameters())[3:], lr=3e-4)
+ws = torch.from_numpy(synth_ws(a.batch, G.num_ws, G.w_dim, 1)).cuda()
+target = torch.zeros(a.batch, 3, G.img_resolution, G.img_resolution, device='cuda')
+def step():
+    out = G.synthesis(ws, noise_mode='const', force_fp32=True)
+    loss = torch.nn.functional.mse_loss(out, target)
+    opt.zero_grad(); loss.backward(); opt.step()
+step(); torch.cuda.synchronize()
+t = time.time()
+for _ in range(a.iters):
+    step()
+torch.cuda.synchronize()
+dt = (time.time() - t) / a.iters
+print(f'{a.cfg} PTI batch {a.batch}: {dt * 1e3:.1f} ms/step  {a.batch / dt:.2f} frames/s  peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB')
