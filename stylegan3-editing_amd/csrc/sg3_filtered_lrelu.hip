@@ -58,8 +58,11 @@ struct StreamParams {
     int totalBlocks;
     float gain, slope, clamp;
     int flip;
+    unsigned char* s;              // sign tensor [N*C][sH][sWb] (2 bits per upsampled sample, 4 per byte), or null
+    int sH, sWb, sx, sy;           // rows, bytes per row, offset of the upsampled buffer inside the sign tensor
 };
 
+__device__ __forceinline__ int to_sgpr_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float to_sgpr(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
@@ -134,8 +137,8 @@ template <int U, int D> struct StreamCfg {
     static constexpr int IWS = GROUPS * 64 + 6;         // input samples a wave needs per row (+ slack)
     static constexpr int NL = (IWS + 63) / 64;          // global loads per lane per row
     static constexpr int SIN = NL * 64;                 // LDS floats for the input row
-    static constexpr int SOUT = 4 + 256 + 16;           // LDS floats for the output row
-    static constexpr int MAXTW = 120;
+    static constexpr int SOUT = 4 + 256 + 32;           // LDS floats for the output row (+ read-ahead of the last lanes)
+    static constexpr int MAXTW = (256 - FD) / D;        // output columns a wave's 256 upsampled columns can complete
 };
 
 // element <-> fp32 through raw buffer instructions: the hardware range check (offset >= num_records reads 0 /
@@ -177,15 +180,21 @@ struct WaveState {
     v2f tuP[Cfg::FU / 2];         // up taps (x U) in REVERSED pairs (tu[2m+1], tu[2m]): the H-up column-pair operands
                                   // as they stand, and the source of the V-up tap splats (odd tap = low half)
     v2f tdP[Cfg::FD / 2];         // down taps (td[2m], td[2m+1]): V-down splats and H-down even/odd pairs
+    unsigned sg[6][U];            // sign-read mode: prefetched sign bytes (this lane's byte | next byte << 8) per upsampled row
+    int soff;                     // sign modes: byte offset, inside a sign row, of the byte holding this lane's first column
+    int sq;                       // sign modes: position (0..3) of that column inside its byte (wave-uniform)
 };
 
-template <typename T, int U, int D, int VPH, int RADIAL>
+// SIGNS: 0 = plain forward; 1 = forward that also writes the sign tensor (training); 2 = adjoint pass: the stored signs
+// replace the nonlinearity (gradient of lrelu + clamp).
+template <typename T, int U, int D, int VPH, int RADIAL, int SIGNS>
 struct Stream {
     typedef StreamCfg<U, D> Cfg;
     typedef WaveState<T, U, D> State;
 
     // issue the loads of input row `i` into st.pre[slot]; rows outside the image get a zero-length descriptor
-    static __device__ __forceinline__ void prefetch(State& st, int slot, const StreamParams& p, const T* __restrict__ plane, int i) {
+    static __device__ __forceinline__ void prefetch(State& st, int slot, const StreamParams& p, const T* __restrict__ plane,
+                                                    const unsigned char* __restrict__ splane, int i) {
         const bool rowOk = (unsigned)i < (unsigned)p.xH;
         const T* row = plane + (long long)i * p.xsH;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)row, (short)0, rowOk ? p.xW * (int)sizeof(T) : 0, 0x00020000);
@@ -193,18 +202,34 @@ struct Stream {
 #pragma unroll
         for (int q = 0; q < Cfg::NL; q++)
             st.pre[slot][q] = __builtin_fmaf(st.bcol[q], rowFlag, bufio<T>::ld(rs, st.coff[q]));
+        if (SIGNS == 2) {
+            // sign bytes of the U upsampled rows this input row will complete (rows / bytes outside the tensor read 0)
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const int sr = U * (i - 5) - (U - 1) + j + p.py0 + p.sy;
+                const bool ok = (unsigned)sr < (unsigned)p.sH;
+                const unsigned char* srow = splane + (ok ? (long long)sr * p.sWb : 0);
+                const __amdgpu_buffer_rsrc_t ss = __builtin_amdgcn_make_buffer_rsrc((void*)srow, (short)0, ok ? p.sWb : 0, 0x00020000);
+                const unsigned b0 = __builtin_amdgcn_raw_buffer_load_b8(ss, st.soff, 0, 0);
+                const unsigned b1 = __builtin_amdgcn_raw_buffer_load_b8(ss, st.soff + 1, 0, 0);
+                st.sg[slot][j] = b0 | (b1 << 8);
+            }
+        }
     }
 
     // one input row: H-up into window slot S, then U upsampled rows through lrelu into the down accumulators
-    template <int S, int HEAD>
+    template <int S>
     static __device__ __forceinline__ void step(State& st, const StreamParams& p, const T* __restrict__ plane, T* __restrict__ oplane,
-                                                lds_f* sIn, lds_f* sOut, int i, int delta, int lane,
+                                                unsigned char* __restrict__ splane, lds_f* sIn, lds_f* sOut, int i, int delta, int lane,
                                                 int oy0, int oy1, int ox0, int oxN, bool pairStore) {
         // ---- input row -> LDS -> this lane's H-upsampled samples ----
         wave_lds_sync();                 // the previous row's sIn reads precede this row's writes
 #pragma unroll
         for (int q = 0; q < Cfg::NL; q++) sIn[lane + 64 * q] = st.pre[S][q];
-        prefetch(st, S, p, plane, i + 6);
+        unsigned sgNow[U];               // this row's sign bytes: the prefetch below reuses their slot
+#pragma unroll
+        for (int j = 0; j < U; j++) sgNow[j] = SIGNS == 2 ? st.sg[S][j] : 0u;
+        prefetch(st, S, p, plane, splane, i + 6);
         wave_lds_sync();
         if (U == 2) {
             float xs[8];
@@ -233,6 +258,7 @@ struct Stream {
         }
         // ---- U new upsampled rows ----
         const float slope = p.slope, clampv = p.clamp / p.gain, gain = p.gain;
+        const float gainOut = (SIGNS == 1) ? 1.f : p.gain;      // sign-write mode applies the gain before the nonlinearity
 #pragma unroll
         for (int j = 0; j < U; j++) {
             const int kv = U - 1 - j;                          // vertical up phase of this row
@@ -253,15 +279,51 @@ struct Stream {
                     u1 = fma_tap<1>(st.w[slot][1], st.tuP[k / 2], u1);
                 }
             }
-            // leaky ReLU (slope <= 1 so lrelu(v) = max(v, slope*v)) and clamp.  The activation gain g > 0 commutes with
-            // both: clamp_c(lrelu(g*u)) = g * clamp_{c/g}(lrelu(u)), so g is applied once per OUTPUT sample after the
-            // down filter instead of once per upsampled sample (clampv = clamp / gain here)
-            const v2f s0 = u0 * splat(slope), s1 = u1 * splat(slope);
-            float a[4] = {__builtin_fmaxf(u0.x, s0.x), __builtin_fmaxf(u0.y, s0.y), __builtin_fmaxf(u1.x, s1.x), __builtin_fmaxf(u1.y, s1.y)};
+            const int uy = U * (i - 5) - (U - 1) + j + p.py0;  // row of the upsampled buffer
+            float a[4] = {u0.x, u0.y, u1.x, u1.y};
+            if (SIGNS == 2) {
+                // adjoint pass: the stored sign codes select the derivative of lrelu + clamp (1, slope or 0); the gain is
+                // linear and applied once per output sample
+                const unsigned bits = sgNow[j] >> (2 * st.sq);
 #pragma unroll
-            for (int c = 0; c < 4; c++) a[c] = __builtin_amdgcn_fmed3f(a[c], -clampv, clampv);
+                for (int c = 0; c < 4; c++) {
+                    const unsigned code = bits >> (2 * c);
+                    a[c] *= (code & 2u) ? 0.f : ((code & 1u) ? slope : 1.f);
+                }
+            } else if (SIGNS == 1) {
+                // training forward: the reference's exact order (gain, lrelu, clamp; filtered_lrelu.cu sign write) so that
+                // the sign codes agree with it: 1 = negative, 2 = clamped
+                unsigned code = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float v = a[c] * gain;
+                    const bool neg = v < 0.f;
+                    const float lv = neg ? v * slope : v;
+                    const bool big = __builtin_fabsf(lv) > p.clamp;
+                    a[c] = big ? __builtin_copysignf(p.clamp, lv) : lv;
+                    code |= (big ? 2u : (neg ? 1u : 0u)) << (2 * c);
+                }
+                const int sr = uy + p.sy;
+                if (uy >= oy0 * D && uy <= (oy1 - 1) * D + Cfg::FD - 1 && (unsigned)sr < (unsigned)p.sH) {    // wave-uniform
+                    // a byte holds 4 consecutive columns; a lane's 4 columns start st.sq columns into a byte, so the byte is
+                    // completed with the first st.sq columns of the next lane
+                    const unsigned nxt = (unsigned)__shfl_down((int)code, 1);
+                    const unsigned byte = st.sq == 0 ? code : ((code >> (2 * (4 - st.sq))) | (nxt << (2 * st.sq))) & 0xffu;
+                    const int bofs = (st.sq == 0 || lane < 63) ? st.soff + (st.sq ? 1 : 0) : -1;
+                    const __amdgpu_buffer_rsrc_t ss = __builtin_amdgcn_make_buffer_rsrc((void*)(splane + (long long)sr * p.sWb), (short)0, p.sWb, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)byte, ss, bofs, 0, 0);
+                }
+            } else {
+                // leaky ReLU (slope <= 1 so lrelu(v) = max(v, slope*v)) and clamp.  The activation gain g > 0 commutes with
+                // both: clamp_c(lrelu(g*u)) = g * clamp_{c/g}(lrelu(u)), so g is applied once per OUTPUT sample after the
+                // down filter instead of once per upsampled sample (clampv = clamp / gain here)
+                const v2f s0 = u0 * splat(slope), s1 = u1 * splat(slope);
+                a[0] = __builtin_fmaxf(u0.x, s0.x); a[1] = __builtin_fmaxf(u0.y, s0.y); a[2] = __builtin_fmaxf(u1.x, s1.x); a[3] = __builtin_fmaxf(u1.y, s1.y);
+#pragma unroll
+                for (int c = 0; c < 4; c++) a[c] = __builtin_amdgcn_fmed3f(a[c], -clampv, clampv);
+            }
             const v2f r0 = {a[0], a[1]}, r1 = {a[2], a[3]};
-            const int kp = (VPH + j) % D;                      // down phase of this row
+            const int kp = (VPH + S * U + j) % D;              // down phase of this row (a trip starts at phase VPH)
             if (RADIAL) {
                 // ---- full 2-D down filter (config R): the activated row is exchanged through LDS once (each lane reads
                 // the 16 samples under its two output columns) and scattered into the six output rows it belongs to, one
@@ -275,7 +337,7 @@ struct Stream {
 #pragma unroll
                 for (int q = 0; q < 4; q++) { const v4f t = srcr[q]; pr[2 * q] = (v2f){t.x, t.y}; pr[2 * q + 1] = (v2f){t.z, t.w}; }
                 wave_lds_sync();
-                const int headR = (HEAD + ((VPH + j) / D)) % 6;
+                const int headR = ((VPH + S * U + j) / D) % 6;
                 constexpr bool FLIPPED = RADIAL == 2;
                 TapRow rowA, rowB;                                 // filter rows in flight: the next one loads under this one's FMAs
                 radial_row_issue(rowA, p.fd, FLIPPED ? kp : 11 - kp);
@@ -300,11 +362,10 @@ struct Stream {
                     }
                 }
                 if (kp == D - 1) {
-                    const int uy = U * (i - 5) - (U - 1) + j + p.py0;
                     const int oy = (uy - (Cfg::FD - 1)) / D;       // exact
                     if (oy >= oy0 && oy < oy1) {                   // wave-uniform
                         const v2f y0 = st.acc[headR][0], y1 = st.acc[headR][1];
-                        const float f0 = (y0.x + y0.y) * gain, f1 = (y1.x + y1.y) * gain;
+                        const float f0 = (y0.x + y0.y) * gainOut, f1 = (y1.x + y1.y) * gainOut;
                         T* orow = oplane + (long long)oy * p.ysH + ox0;
                         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)orow, (short)0, oxN * (int)sizeof(T), 0x00020000);
                         if (pairStore) {
@@ -318,7 +379,7 @@ struct Stream {
                 continue;
             }
             // scatter into the FD/D output rows this upsampled row belongs to
-            const int headNow = (HEAD + ((VPH + j) / D)) % 6;  // completions so far in this step shift the head
+            const int headNow = ((VPH + S * U + j) / D) % 6;   // output rows completed so far in this trip shift the head
 #pragma unroll
             for (int r = 0; r < 6; r++) {
                 const int slot = (headNow + 5 - r) % 6;        // r = 5: oldest output row (completes first)
@@ -336,29 +397,39 @@ struct Stream {
             }
             if (kp == D - 1) {
                 // output row complete: H-down through LDS and store
-                const int uy = U * (i - 5) - (U - 1) + j + p.py0;
                 const int oy = (uy - (Cfg::FD - 1)) / D;       // exact
                 if (oy >= oy0 && oy < oy1) {                   // wave-uniform
                     const v2f o0 = st.acc[headNow][0], o1 = st.acc[headNow][1];
                     lds_f* dst = sOut + (4 - delta) + 4 * lane;
                     dst[0] = o0.x; dst[1] = o0.y; dst[2] = o1.x; dst[3] = o1.y;
                     wave_lds_sync();
-                    // lane l -> output columns 2l, 2l+1: upsampled samples 4l .. 4l+13 (+4 pad), four aligned b128 reads
-                    const lds_v4f* src = reinterpret_cast<const lds_v4f*>(sOut + 4 + 4 * lane);
-                    v2f pr[8];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { const v4f t = src[q]; pr[2 * q] = (v2f){t.x, t.y}; pr[2 * q + 1] = (v2f){t.z, t.w}; }
-                    v2f y0 = pr[0] * st.tdP[0], y1 = pr[1] * st.tdP[0];
-#pragma unroll
-                    for (int q = 1; q < Cfg::FD / 2; q++) { y0 = fma2(pr[q], st.tdP[q], y0); y1 = fma2(pr[q + 1], st.tdP[q], y1); }
-                    const float f0 = (y0.x + y0.y) * gain, f1 = (y1.x + y1.y) * gain;
                     T* orow = oplane + (long long)oy * p.ysH + ox0;
                     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)orow, (short)0, oxN * (int)sizeof(T), 0x00020000);
-                    if (pairStore) {
-                        bufio<T>::st2(rs, 2 * lane * (int)sizeof(T), f0, f1);
+                    const lds_v4f* src = reinterpret_cast<const lds_v4f*>(sOut + 4 + 4 * lane);
+                    if (D == 2) {
+                        // lane l -> output columns 2l, 2l+1: upsampled samples 4l .. 4l+13 (+4 pad), four aligned b128 reads
+                        v2f pr[8];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { const v4f t = src[q]; pr[2 * q] = (v2f){t.x, t.y}; pr[2 * q + 1] = (v2f){t.z, t.w}; }
+                        v2f y0 = pr[0] * st.tdP[0], y1 = pr[1] * st.tdP[0];
+#pragma unroll
+                        for (int q = 1; q < Cfg::FD / 2; q++) { y0 = fma2(pr[q], st.tdP[q], y0); y1 = fma2(pr[q + 1], st.tdP[q], y1); }
+                        const float f0 = (y0.x + y0.y) * gainOut, f1 = (y1.x + y1.y) * gainOut;
+                        if (pairStore) {
+                            bufio<T>::st2(rs, 2 * lane * (int)sizeof(T), f0, f1);
+                        } else {
+                            bufio<T>::st1(rs, 2 * lane * (int)sizeof(T), f0);
+                            bufio<T>::st1(rs, (2 * lane + 1) * (int)sizeof(T), f1);
+                        }
                     } else {
-                        bufio<T>::st1(rs, 2 * lane * (int)sizeof(T), f0);
-                        bufio<T>::st1(rs, (2 * lane + 1) * (int)sizeof(T), f1);
+                        // D == 4: lane l -> output column l: upsampled samples 4l .. 4l+23, six aligned b128 reads
+                        v2f pr[12];
+#pragma unroll
+                        for (int q = 0; q < 6; q++) { const v4f t = src[q]; pr[2 * q] = (v2f){t.x, t.y}; pr[2 * q + 1] = (v2f){t.z, t.w}; }
+                        v2f y0 = pr[0] * st.tdP[0];
+#pragma unroll
+                        for (int q = 1; q < Cfg::FD / 2; q++) y0 = fma2(pr[q], st.tdP[q], y0);
+                        bufio<T>::st1(rs, lane * (int)sizeof(T), (y0.x + y0.y) * gainOut);
                     }
                     wave_lds_sync();
                 }
@@ -367,7 +438,8 @@ struct Stream {
     }
 
     static __device__ __forceinline__ void run(const StreamParams& p) {
-        static_assert(U % D == 0 && D == 2, "streaming kernel: down must be 2 and divide up");
+        static_assert((D == 2 || D == 4) && (6 * U) % D == 0, "streaming kernel: down is 2 or 4");
+        static_assert(RADIAL == 0 || (D == 2 && SIGNS == 0), "radial variant: plain forward, down 2");
         __shared__ __attribute__((aligned(16))) float lds[Cfg::SIN + Cfg::SOUT];
         lds_f* sIn = (lds_f*)lds;
         lds_f* sOut = (lds_f*)lds + Cfg::SIN;                               // row exchanged for the horizontal down pass
@@ -391,7 +463,8 @@ struct Stream {
 
         const T* plane = (const T*)p.x + (long long)n * p.xsN + (long long)c * p.xsC;
         T* oplane = (T*)p.y + (long long)n * p.ysN + (long long)c * p.ysC;
-        const float bias = io<T>::ld((const T*)p.b + (long long)c * p.bStride);
+        const float bias = p.b ? io<T>::ld((const T*)p.b + (long long)c * p.bStride) : 0.f;
+        unsigned char* splane = SIGNS ? p.s + (long long)plane_id * p.sH * p.sWb : nullptr;
         // a pair store must not straddle the end of the row (and fp16 pairs must be dword aligned)
         const bool pairStore = ((oxN & 1) == 0) &&
             (sizeof(T) == 4 || (((((unsigned long long)oplane >> 1) + (unsigned long long)ox0) & 1) == 0 && (p.ysH & 1) == 0));
@@ -427,10 +500,19 @@ struct Stream {
             st.bcol[q] = ((unsigned)ix < (unsigned)p.xW) ? bias : 0.f;
         }
 
+        if (SIGNS) {
+            const int c0 = uxs + p.sx;                           // sign-tensor column of lane 0's first upsampled column
+            st.sq = to_sgpr_i(((c0 % 4) + 4) % 4);
+            st.soff = floor_div(c0, 4) + lane;
+        } else {
+            st.sq = 0; st.soff = 0;
+        }
+
         // vertical geometry
         const int uyA = oy0 * D;
         const int uyB = (oy1 - 1) * D + Cfg::FD - 1;
-        const int iFirst = ceil_div_s(uyA - p.py0, U);          // first input row of the window that yields uyA
+        int iFirst = ceil_div_s(uyA - p.py0, U);                // first input row of the window that yields uyA
+        if ((U * (iFirst - 5)) % D != 0) iFirst -= 1;           // trips start at down phase VPH: U * (iFirst - 5) = 0 (mod D)
         const int iLast = ceil_div_s(uyB - p.py0, U) + 5;       // step that yields uyB
         const int nBlocks = (iLast - iFirst + 1 + 5) / 6;
 
@@ -438,26 +520,33 @@ struct Stream {
         for (int s = 0; s < 6; s++) {
             st.w[s][0] = splat(0.f); st.w[s][1] = splat(0.f);
             st.acc[s][0] = splat(0.f); st.acc[s][1] = splat(0.f);
-            prefetch(st, s, p, plane, iFirst + s);
+            prefetch(st, s, p, plane, splane, iFirst + s);
         }
 
-        constexpr int ADV = U / D;                               // output rows completed per input row
         int i = iFirst;
         for (int blk = 0; blk < nBlocks; blk++, i += 6) {
-            step<0, (0 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 0, delta, lane, oy0, oy1, ox0, oxN, pairStore);
-            step<1, (1 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 1, delta, lane, oy0, oy1, ox0, oxN, pairStore);
-            step<2, (2 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 2, delta, lane, oy0, oy1, ox0, oxN, pairStore);
-            step<3, (3 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 3, delta, lane, oy0, oy1, ox0, oxN, pairStore);
-            step<4, (4 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 4, delta, lane, oy0, oy1, ox0, oxN, pairStore);
-            step<5, (5 * ADV) % 6>(st, p, plane, oplane, sIn, sOut, i + 5, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<0>(st, p, plane, oplane, splane, sIn, sOut, i + 0, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<1>(st, p, plane, oplane, splane, sIn, sOut, i + 1, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<2>(st, p, plane, oplane, splane, sIn, sOut, i + 2, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<3>(st, p, plane, oplane, splane, sIn, sOut, i + 3, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<4>(st, p, plane, oplane, splane, sIn, sOut, i + 4, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            step<5>(st, p, plane, oplane, splane, sIn, sOut, i + 5, delta, lane, oy0, oy1, ox0, oxN, pairStore);
+            if ((6 * U / D) % 6 != 0) {
+                // a trip completes 6U/D output rows; when that is 3 (U = 2, D = 4) the ring of output rows has turned by
+                // half: swap the halves so that the compile-time slot numbering holds for the next trip
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) { const v2f t = st.acc[r][h]; st.acc[r][h] = st.acc[r + 3][h]; st.acc[r + 3][h] = t; }
+            }
         }
     }
 };
 
-template <typename T, int U, int D, int VPH, int RADIAL>
+template <typename T, int U, int D, int VPH, int RADIAL, int SIGNS>
 __global__ void __launch_bounds__(64)
 flrelu_stream_kernel(StreamParams p) {
-    Stream<T, U, D, VPH, RADIAL>::run(p);
+    Stream<T, U, D, VPH, RADIAL, SIGNS>::run(p);
 }
 
 // ---------------------------------------------------------------------------
@@ -484,7 +573,7 @@ flrelu_pointwise_kernel(PointParams p) {
         const int ix = ox - p.px0, iy = oy - p.py0;
         float v = 0.f;
         if ((unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H)
-            v = io<T>::ld((const T*)p.x + n * p.xs[0] + c * p.xs[1] + iy * p.xs[2] + ix * p.xs[3]) + io<T>::ld((const T*)p.b + c * p.bStride);
+            v = io<T>::ld((const T*)p.x + n * p.xs[0] + c * p.xs[1] + iy * p.xs[2] + ix * p.xs[3]) + (p.b ? io<T>::ld((const T*)p.b + c * p.bStride) : 0.f);
         v *= fu * p.gain;
         v = v < 0.f ? v * p.slope : v;
         v = fminf(fmaxf(v, -p.clamp), p.clamp);
@@ -496,13 +585,18 @@ flrelu_pointwise_kernel(PointParams p) {
 static bool stream_supported(int up, int down, int fuW, int fuH, int fdW, int fdH) {
     if (fuH != 0) return false;                               // separable up filter
     if (fdH != 0 && fdH != 12) return false;                  // separable, or full 12x12 (radial) down filter
-    if (down != 2 || fdW != 12) return false;
-    return (up == 2 && fuW == 12) || (up == 4 && fuW == 24);
+    if (down == 2 && fdW == 12) return (up == 2 && fuW == 12) || (up == 4 && fuW == 24);
+    // adjoint of the up-4 layers: up 2 (12 taps), down 4 (24 taps), separable
+    return down == 4 && fdW == 24 && fdH == 0 && up == 2 && fuW == 12;
 }
 
 // the streaming kernel evaluates lrelu as max(v, slope * v), valid for 0 <= slope <= 1 (every StyleGAN3 layer)
 static bool stream_params_ok(const sg3_filtered_lrelu_params& q) {
     if (q.fdH != 0 && ((uintptr_t)q.fd & 15) != 0) return false;  // radial taps are fetched as 16-byte scalar quads
+    const bool signs = q.writeSigns || q.readSigns;
+    if (signs && (q.fdH != 0 || !q.s || q.sH <= 0 || q.sWbytes <= 0)) return false;      // sign modes: separable filters only
+    if (q.readSigns && q.up != 2) return false;                                            // adjoint passes upsample by 2
+    if (q.down == 4 && !q.readSigns) return false;                                         // down 4 exists for the adjoint only
     return q.slope >= 0.f && q.slope <= 1.f && q.xStride[3] == 1 && q.yStride[3] == 1 && !(q.clamp < 0.f);
 }
 
@@ -521,8 +615,9 @@ static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
     p.px0 = q.px0; p.py0 = q.py0;
     p.gain = q.gain; p.slope = q.slope; p.clamp = q.clamp; p.flip = q.flip;
 
-    // strips: equal widths <= 120 columns
-    const int maxTW = 120;
+    p.s = q.s; p.sH = q.sH; p.sWb = q.sWbytes; p.sx = q.sx; p.sy = q.sy;
+    // strips: equal widths, as wide as a wave's 256 upsampled columns can complete (120 for down 2, 58 for down 4)
+    const int maxTW = (256 - 6 * q.down) / q.down;
     p.nStrips = ceil_div(q.yW, maxTW);
     p.TW = ceil_div(q.yW, p.nStrips);
     // row chunks: enough waves to fill 256 CUs x 16 waves a few times over, but chunks tall enough that the
@@ -541,13 +636,25 @@ static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
 
     const int vph = (((q.py0 - (q.up - 1)) % q.down) + q.down) % q.down;
     dim3 g((unsigned)total), b(64);
-#define SG3_STREAM_LAUNCH(U, V, R) hipLaunchKernelGGL((flrelu_stream_kernel<T, U, 2, V, R>), g, b, 0, st, p)
-    const int variant = q.fdH == 0 ? 0 : (q.flip ? 2 : 1);         // separable | radial | radial with flipped taps
-#define SG3_STREAM_LAUNCH_V(U, R) do { if (vph == 0) SG3_STREAM_LAUNCH(U, 0, R); else SG3_STREAM_LAUNCH(U, 1, R); } while (0)
-    if (q.up == 2) {
-        if (variant == 0) SG3_STREAM_LAUNCH_V(2, 0); else if (variant == 1) SG3_STREAM_LAUNCH_V(2, 1); else SG3_STREAM_LAUNCH_V(2, 2);
+#define SG3_STREAM_LAUNCH(U, D, V, R, S) hipLaunchKernelGGL((flrelu_stream_kernel<T, U, D, V, R, S>), g, b, 0, st, p)
+#define SG3_STREAM_LAUNCH_V(U, R, S) do { if (vph == 0) SG3_STREAM_LAUNCH(U, 2, 0, R, S); else SG3_STREAM_LAUNCH(U, 2, 1, R, S); } while (0)
+    if (q.readSigns) {
+        if (q.down == 2) SG3_STREAM_LAUNCH_V(2, 0, 2);
+        else switch (vph) {
+            case 0: SG3_STREAM_LAUNCH(2, 4, 0, 0, 2); break;
+            case 1: SG3_STREAM_LAUNCH(2, 4, 1, 0, 2); break;
+            case 2: SG3_STREAM_LAUNCH(2, 4, 2, 0, 2); break;
+            default: SG3_STREAM_LAUNCH(2, 4, 3, 0, 2); break;
+        }
+    } else if (q.writeSigns) {
+        if (q.up == 2) SG3_STREAM_LAUNCH_V(2, 0, 1); else SG3_STREAM_LAUNCH_V(4, 0, 1);
     } else {
-        if (variant == 0) SG3_STREAM_LAUNCH_V(4, 0); else if (variant == 1) SG3_STREAM_LAUNCH_V(4, 1); else SG3_STREAM_LAUNCH_V(4, 2);
+        const int variant = q.fdH == 0 ? 0 : (q.flip ? 2 : 1);     // separable | radial | radial with flipped taps
+        if (q.up == 2) {
+            if (variant == 0) SG3_STREAM_LAUNCH_V(2, 0, 0); else if (variant == 1) SG3_STREAM_LAUNCH_V(2, 1, 0); else SG3_STREAM_LAUNCH_V(2, 2, 0);
+        } else {
+            if (variant == 0) SG3_STREAM_LAUNCH_V(4, 0, 0); else if (variant == 1) SG3_STREAM_LAUNCH_V(4, 1, 0); else SG3_STREAM_LAUNCH_V(4, 2, 0);
+        }
     }
 #undef SG3_STREAM_LAUNCH_V
 #undef SG3_STREAM_LAUNCH
@@ -609,7 +716,7 @@ int sg3_filtered_lrelu_shape(int xH, int xW, int up, int down, int fuW, int fuH,
 
 int sg3_filtered_lrelu(const sg3_filtered_lrelu_params* p, void* stream) {
     using namespace sg3;
-    SG3_REQUIRE(p && p->x && p->y && p->b && p->fu && p->fd, "filtered_lrelu: null tensor");
+    SG3_REQUIRE(p && p->x && p->y && p->fu && p->fd, "filtered_lrelu: null tensor");
     SG3_REQUIRE(p->N > 0 && p->C > 0 && p->xH > 0 && p->xW > 0, "filtered_lrelu: x is empty");
     SG3_REQUIRE(p->yH > 0 && p->yW > 0, "filtered_lrelu: output must be at least 1x1");
     SG3_REQUIRE(p->up >= 1 && p->down >= 1, "filtered_lrelu: up and down must be at least 1");
@@ -619,7 +726,7 @@ int sg3_filtered_lrelu(const sg3_filtered_lrelu_params* p, void* stream) {
     const bool signs = p->writeSigns || p->readSigns;
     if (!signs && pointwise_supported(p->up, p->down, p->fuW, p->fuH, p->fdW, p->fdH))
         return p->dtype == SG3_F32 ? launch_pointwise<float>(*p, st) : launch_pointwise<_Float16>(*p, st);
-    if (!signs && stream_supported(p->up, p->down, p->fuW, p->fuH, p->fdW, p->fdH) && stream_params_ok(*p))
+    if (stream_supported(p->up, p->down, p->fuW, p->fuH, p->fdW, p->fdH) && stream_params_ok(*p))
         return p->dtype == SG3_F32 ? launch_stream<float>(*p, st) : launch_stream<_Float16>(*p, st);
     set_error("filtered_lrelu: no fused kernel for up=%d down=%d fu=%dx%d fd=%dx%d signs=%d", p->up, p->down,
               p->fuW, p->fuH, p->fdW, p->fdH, (int)signs);

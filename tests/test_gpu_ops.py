@@ -143,6 +143,52 @@ def test_filtered_lrelu_backward(name):
         assert maxabs(b.grad.cpu().numpy(), g[name + '/db']) <= 2e-3
 
 
+@pytest.mark.parametrize('shape,up,taps,pad,clamp', [
+    ((1, 2, 150, 150), 2, 12, [9, 8, 9, 8], 256),            # T up-2 layer: 2 strips forward; adjoint down 2
+    ((2, 2, 86, 86), 4, 24, [-6, -9, -6, -9], 256),           # T up-4 layer: adjoint is up 2 / down 4, 2+ strips of 58
+    ((1, 1, 278, 130), 2, 12, [9, 8, 9, 8], 0.7),             # several row chunks, tight clamp (code 2 frequent)
+    ((1, 1, 120, 278), 4, 24, [-6, -9, -6, -9], None),        # no clamp, wide: 5 adjoint strips
+])
+def test_filtered_lrelu_fused_sign_kernels(shape, up, taps, pad, clamp):
+    """Training forward (fused kernel writing the 2-bit sign tensor) and its adjoint (fused kernel reading it, incl. the
+    up-2 / down-4 form) against autograd through the reference formulation on the CPU (`impl='ref'`)."""
+    from oracle import oracle as O
+    from torch_utils.ops import filtered_lrelu as fl
+    fl._init()
+    fs = 64
+    fu = O.design_lowpass_filter(taps, 4.0, 8.0, fs * up / 2)
+    fd = O.design_lowpass_filter(12, 5.0, 9.0, fs)
+    xn, bn = rand(3, *shape), rand(4, shape[1])
+    kw = dict(up=up, down=2, padding=pad, gain=float(np.sqrt(2)), slope=0.2, clamp=clamp, flip_filter=False)
+    # the fused kernel accepts the sign-writing call (return code 0) and produces the sign tensor
+    cl = float('inf') if clamp is None else clamp
+    y0, so, rc = fl._plugin.filtered_lrelu(T(xn), T(fu), T(fd), T(bn), torch.empty(0), up, 2, *pad, 0, 0, kw['gain'], 0.2, cl, False, True)
+    assert rc == 0 and so.dtype == torch.uint8 and so.numel() > 0
+    xr = torch.from_numpy(xn).requires_grad_(True); br = torch.from_numpy(bn).requires_grad_(True)
+    yr = fl.filtered_lrelu(xr, torch.from_numpy(fu), torch.from_numpy(fd), br, impl='ref', **kw)
+    gy = rand(5, *yr.shape)
+    (yr * torch.from_numpy(gy)).sum().backward()
+    x = T(xn).requires_grad_(True); b = T(bn).requires_grad_(True)
+    y = fl.filtered_lrelu(x, T(fu), T(fd), b, **kw)
+    (y * T(gy)).sum().backward()
+    assert maxabs(y0.cpu().numpy(), yr.detach().numpy()) <= 2e-5
+    assert maxabs(y.detach().cpu().numpy(), yr.detach().numpy()) <= 2e-5
+    assert maxabs(x.grad.cpu().numpy(), xr.grad.numpy()) <= 5e-5
+    assert maxabs(b.grad.cpu().numpy(), br.grad.numpy()) <= 2e-3 * max(1.0, float(br.grad.abs().max()))
+    # sign codes against the generic composition's (upfirdn2d + filtered_lrelu_act_): equal except where the upsampled
+    # value is within rounding of zero / of the clamp
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        from torch_utils.ops import upfirdn2d
+        u = upfirdn2d.upfirdn2d(T(xn) + T(bn)[None, :, None, None], T(fu), up=up, padding=pad, gain=up ** 2)
+    so_ref = fl._plugin.filtered_lrelu_act_(u.clone(), torch.empty(0), 0, 0, kw['gain'], 0.2, cl, True)
+    assert so.shape == so_ref.shape
+    wact = u.shape[3] // 4                                   # whole bytes inside the active width
+    diff = (so[:, :, :u.shape[2], :wact] != so_ref[:, :, :u.shape[2], :wact]).float().mean()
+    assert float(diff) <= 1e-4, float(diff)
+
+
 def test_filtered_lrelu_act_signs_roundtrip():
     """filtered_lrelu_act_: written signs reproduce the activation derivative when read back."""
     from torch_utils.ops import filtered_lrelu
