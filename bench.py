@@ -166,6 +166,7 @@ def bench_extras(G, ws, device, steps=5):
         dt = (time.perf_counter() - t0) / steps
         return {'imgs_per_s': int(w.shape[0]) / dt, 'ms_per_step': dt * 1e3, 'batch': int(w.shape[0])}
 
+    G.synthesis.input.transform = torch.eye(3, device=device)     # the inversion measurement leaves per-frame transforms behind
     out = {'T1024_mixed_fp16': run(G, ws)}
     for cfg, batch in (('R1024', 4), ('R512', 8)):
         gen = build_generator(cfg, device)

@@ -259,6 +259,8 @@ typedef struct sg3_modconv_prep_params {
     float          xBound;     /* f16x3 only: max |x| the conv will see (> 0).  sIn is scaled by a power of two per
                                 * sample so that |x * sIn| stays below 2^15, and dcoef (required, also without
                                 * demodulation) carries the inverse */
+    const float*   xBoundDev;  /* optional DEVICE pointer to that bound (overrides xBound when not NULL): lets a caller
+                                * derive it on the device, e.g. max |dy| of a gradient, without a host round trip */
 } sg3_modconv_prep_params;
 
 SG3_API int sg3_modulated_conv2d_prep(const sg3_modconv_prep_params* p, void* stream);

@@ -733,16 +733,16 @@ modconv_prep_s_kernel(sg3_modconv_prep_params p) {
         s2[p.I + i] = v;
         smax = fmaxf(smax, fabsf(v));
     }
-    // f16x3 / f16: per-sample power-of-two scale keeping |x * sIn| below 2^15
+    // f16x3 / f16: per-sample power-of-two scale bringing max |x * sIn| just below 2^15
     float down = 1.f, up = 1.f;
     if (p.precision != SG3_CONV_FP32) {
         __syncthreads();
         red[threadIdx.x] = smax;
         __syncthreads();
         for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]); __syncthreads(); }
-        const float peak = red[0] * p.xBound;
+        const float peak = red[0] * (p.xBoundDev ? p.xBoundDev[0] : p.xBound);
         int e = 0;
-        if (peak > 32768.f) e = (int)ceilf(log2f(peak / 32768.f));
+        if (peak > 0.f && peak < 3.0e38f) e = (int)ceilf(log2f(peak / 32768.f));    // either direction: tiny operands (gradients) are scaled up
         down = ldexpf(1.f, -e); up = ldexpf(1.f, e);
     }
     __syncthreads();
@@ -879,7 +879,7 @@ int sg3_modulated_conv2d_prep(const sg3_modconv_prep_params* p, void* stream) {
     SG3_REQUIRE((size_t)p->I * 2 * sizeof(float) <= 48 * 1024, "modulated_conv2d_prep: too many input channels");
     SG3_REQUIRE(p->precision == SG3_CONV_FP32 || p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16, "modulated_conv2d_prep: bad precision");
     if (p->precision != SG3_CONV_FP32) {
-        SG3_REQUIRE(p->xBound > 0.f && p->dcoef, "modulated_conv2d_prep: f16x3 needs xBound > 0 and a dcoef buffer");
+        SG3_REQUIRE((p->xBound > 0.f || p->xBoundDev) && p->dcoef, "modulated_conv2d_prep: f16x3 needs xBound > 0 and a dcoef buffer");
     }
     hipStream_t st = (hipStream_t)stream;
     const int kc = packed_kc(p->k);

@@ -58,7 +58,8 @@ class ModconvParams(ctypes.Structure):
 class ModconvPrepParams(ctypes.Structure):
     _fields_ = [('w', c_vp), ('s', c_vp), ('wPacked', c_vp), ('wsq', c_vp), ('sIn', c_vp), ('dcoef', c_vp),
                 ('inputGain', c_vp), ('inputGainMode', c_i32),
-                ('N', c_i32), ('I', c_i32), ('O', c_i32), ('k', c_i32), ('demodulate', c_i32), ('precision', c_i32), ('xBound', c_f32)]
+                ('N', c_i32), ('I', c_i32), ('O', c_i32), ('k', c_i32), ('demodulate', c_i32), ('precision', c_i32), ('xBound', c_f32),
+                ('xBoundDev', c_vp)]
 
 
 class Conv2dParams(ctypes.Structure):

@@ -48,7 +48,25 @@ def _composite(x, w, s, demodulate, padding, input_gain):
     return y.reshape(n, -1, *y.shape[2:])
 
 
-def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None):
+def _effective_weights(w, s, demodulate, input_gain, n):
+    """Per-sample weights of the reference formulation (networks_stylegan3.py:39-56), [N,O,I,k,k]: a small tensor whose
+    autograd graph carries the gradients of w, s and input_gain."""
+    i = w.shape[1]
+    if demodulate:
+        w = w * w.square().mean([1, 2, 3], keepdim=True).rsqrt()
+        s = s * s.square().mean().rsqrt()
+    w = w.unsqueeze(0) * s.unsqueeze(1).unsqueeze(3).unsqueeze(4)
+    if demodulate:
+        w = w * (w.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt().unsqueeze(2).unsqueeze(3).unsqueeze(4)
+    if input_gain is not None:
+        w = w * input_gain.expand(n, i).unsqueeze(1).unsqueeze(3).unsqueeze(4)
+    return w
+
+
+def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None, x_bound_dev=None, out_scale=None):
+    """prep + implicit-GEMM kernels.  Returns (out, sIn [N,I], dcoef [N,O] or None): the two per-sample scale vectors are
+    what the data-gradient pass needs.  `x_bound_dev`: one-element device tensor holding the bound; `out_scale` [N,O]: extra
+    per-sample output-channel scale folded into the epilogue coefficient."""
     n, ci, h, wd = (int(v) for v in x.shape)
     co, ci2, k, k2 = (int(v) for v in w.shape)
     if k != k2 or ci != ci2 or k not in (1, 3):
@@ -71,9 +89,10 @@ def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None):
         else:
             gmode, g = 3, g.expand(n, ci).contiguous()
         gptr = g
-    if x.dtype == torch.float16 and x_bound is None:
+    if x.dtype == torch.float16 and x_bound is None and x_bound_dev is None:
         x_bound = 65504.0                                   # the dtype's own range
-    split = precision == 'f16x3' and (k == 3 or (padding == 0 and co > 4)) and x_bound is not None and x_bound > 0   # ToRGB (O <= 4) is HBM-bound: plain kernel
+    bounded = x_bound_dev is not None or (x_bound is not None and x_bound > 0)
+    split = precision == 'f16x3' and (k == 3 or (padding == 0 and co > 4)) and bounded   # ToRGB (O <= 4) is HBM-bound: plain kernel
     prec = (abi.SG3_CONV_F16 if x.dtype == torch.float16 else abi.SG3_CONV_F16X3) if split else abi.SG3_CONV_FP32
     wn = torch.empty([int(lib.sg3_modconv_packed_floats(co, ci, k, prec))], dtype=torch.float32, device=dev)
     wsq = torch.empty([co, ci], dtype=torch.float32, device=dev)
@@ -87,41 +106,90 @@ def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None):
         pp.w, pp.s, pp.wPacked, pp.wsq, pp.sIn, pp.dcoef = abi.ptr(w32), abi.ptr(s32), abi.ptr(wn), abi.ptr(wsq), abi.ptr(s_in), abi.ptr(dcoef)
         pp.inputGain, pp.inputGainMode = abi.ptr(gptr), gmode
         pp.N, pp.I, pp.O, pp.k, pp.demodulate = n, ci, co, k, int(bool(demodulate))
-        pp.precision, pp.xBound = prec, float(x_bound) if split else 0.0
+        pp.precision = prec
+        pp.xBound = float(x_bound) if (split and x_bound_dev is None) else 0.0
+        pp.xBoundDev = abi.ptr(x_bound_dev) if (split and x_bound_dev is not None) else None
         abi.check(lib.sg3_modulated_conv2d_prep(ctypes.byref(pp), stream), 'sg3_modulated_conv2d_prep')
+        coef = dcoef
+        if out_scale is not None:
+            coef = out_scale.to(torch.float32).contiguous() if dcoef is None else dcoef * out_scale
         cp = abi.ModconvParams()
-        cp.x, cp.wPacked, cp.sIn, cp.dcoef, cp.out = abi.ptr(x), abi.ptr(wn), abi.ptr(s_in), abi.ptr(dcoef), abi.ptr(out)
+        cp.x, cp.wPacked, cp.sIn, cp.dcoef, cp.out = abi.ptr(x), abi.ptr(wn), abi.ptr(s_in), abi.ptr(coef), abi.ptr(out)
         cp.dtype = abi.dtype_code(x.dtype)
         cp.N, cp.I, cp.O, cp.H, cp.W, cp.k, cp.pad = n, ci, co, h, wd, k, int(padding)
         cp.precision = prec
         abi.check(lib.sg3_modulated_conv2d(ctypes.byref(cp), stream), 'sg3_modulated_conv2d')
-    return out
+    return out, s_in, dcoef
+
+
+def _data_gradient(dy, w, s_in, dcoef, demodulate, padding):
+    """dx of the modulated convolution on the same implicit-GEMM kernels: with out = d * conv(wn, x * sIn),
+    dx = sIn * conv(flip(wn)^T, dy * d) with padding k-1-pad -- the forward kernel with the roles of the two per-sample
+    scale vectors exchanged.  The bound the split-precision path needs is max |dy|, taken on the device."""
+    n, co = int(dy.shape[0]), int(w.shape[0])
+    k = int(w.shape[2])
+    wn = w.detach().to(torch.float32)
+    if demodulate:
+        wn = wn * wn.square().mean([1, 2, 3], keepdim=True).rsqrt()
+    wt = wn.flip([2, 3]).transpose(0, 1).contiguous()                         # [I,O,k,k]
+    mod = dcoef if dcoef is not None else torch.ones([n, co], dtype=torch.float32, device=dy.device)
+    bound = dy.detach().abs().amax().to(torch.float32).reshape(1)
+    dx, _, _ = _launch(dy, wt, mod, False, k - 1 - padding, None, x_bound_dev=bound, out_scale=s_in)
+    return dx
 
 
 class _ModulatedConv2dHip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, s, input_gain, demodulate, padding, x_bound):  # pylint: disable=arguments-differ
-        ctx.save_for_backward(x, w, s, input_gain if input_gain is not None else torch.empty(0))
+        out, s_in, dcoef = _launch(x, w, s, demodulate, padding, input_gain, x_bound)
+        ctx.save_for_backward(x, w, s, input_gain if input_gain is not None else torch.empty(0), s_in,
+                              dcoef if dcoef is not None else torch.empty(0))
         ctx.cfg = (demodulate, padding, input_gain is not None)
-        return _launch(x, w, s, demodulate, padding, input_gain, x_bound)
+        return out
 
     @staticmethod
     def backward(ctx, dy):  # pylint: disable=arguments-differ
-        x, w, s, g = ctx.saved_tensors
+        x, w, s, g, s_in, dcoef = ctx.saved_tensors
         demodulate, padding, has_gain = ctx.cfg
         need = ctx.needs_input_grad
-        ins, idx = [], []
-        with torch.enable_grad():
-            xd = x.detach().requires_grad_(need[0]); wd = w.detach().requires_grad_(need[1]); sd = s.detach().requires_grad_(need[2])
-            gd = g.detach().requires_grad_(need[3]) if has_gain else None
-            for j, t in enumerate((xd, wd, sd, gd)):
+        out = [None] * 7
+        if torch.is_grad_enabled():
+            # higher-order gradients: differentiate the reference formulation itself
+            ins, idx = [], []
+            with torch.enable_grad():
+                xd = x.detach().requires_grad_(need[0]); wd = w.detach().requires_grad_(need[1]); sd = s.detach().requires_grad_(need[2])
+                gd = g.detach().requires_grad_(need[3]) if has_gain else None
+                for j, t in enumerate((xd, wd, sd, gd)):
+                    if t is not None and need[j]:
+                        ins.append(t); idx.append(j)
+                y = _composite(xd, wd, sd, demodulate, padding, gd)
+                grads = torch.autograd.grad(y, ins, dy, create_graph=True, allow_unused=True) if ins else []
+            for j, gr in zip(idx, grads):
+                out[j] = gr
+            return tuple(out)
+        dy = dy.contiguous()
+        n = int(x.shape[0])
+        co, ci, k, _ = (int(v) for v in w.shape)
+        if need[0]:
+            out[0] = _data_gradient(dy, w, s_in, dcoef if dcoef.numel() else None, demodulate, padding)
+        if need[1] or need[2] or (has_gain and need[3]):
+            # gradient of the per-sample effective weights (a grouped weight-gradient convolution), then the chain rule
+            # through the small [N,O,I,k,k] tensor for w, s and input_gain
+            with torch.enable_grad():
+                wd = w.detach().requires_grad_(need[1]); sd = s.detach().requires_grad_(need[2])
+                gd = g.detach().requires_grad_(need[3]) if has_gain else None
+                w_eff = _effective_weights(wd.float(), sd.float(), demodulate, gd, n)
+            wv = w_eff.detach().reshape(n * co, ci, k, k).to(x.dtype)
+            _, dw_eff, _ = torch.ops.aten.convolution_backward(
+                dy.reshape(1, n * co, *dy.shape[2:]), x.reshape(1, n * ci, *x.shape[2:]), wv, None,
+                [1, 1], [padding, padding], [1, 1], False, [0, 0], n, [False, True, False])
+            ins, idx = [], []
+            for j, t in ((1, wd), (2, sd), (3, gd)):
                 if t is not None and need[j]:
                     ins.append(t); idx.append(j)
-            y = _composite(xd, wd, sd, demodulate, padding, gd)
-            grads = torch.autograd.grad(y, ins, dy, create_graph=torch.is_grad_enabled(), allow_unused=True) if ins else []
-        out = [None] * 7
-        for j, gr in zip(idx, grads):
-            out[j] = gr
+            grads = torch.autograd.grad(w_eff, ins, dw_eff.reshape_as(w_eff).to(w_eff.dtype), allow_unused=True)
+            for j, gr in zip(idx, grads):
+                out[j] = gr
         return tuple(out)
 
 

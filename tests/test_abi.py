@@ -88,7 +88,8 @@ def test_shape_errors_and_kernel_table():
     assert lib.sg3_modconv_packed_floats(81, 128, 3, _sg3abi.SG3_CONV_FP32) == 81 * 16 * 9 * 8
     assert lib.sg3_modconv_packed_floats(3, 32, 1, _sg3abi.SG3_CONV_FP32) == 3 * 2 * 16
     assert lib.sg3_modconv_packed_floats(81, 128, 3, _sg3abi.SG3_CONV_F16X3) == 81 * 8 * 9 * 16     # hi|lo halfs
-    assert lib.sg3_modconv_packed_floats(3, 32, 1, _sg3abi.SG3_CONV_F16X3) == 0                     # 3x3 only
+    assert lib.sg3_modconv_packed_floats(645, 406, 1, _sg3abi.SG3_CONV_F16X3) == 645 * 26 * 16           # 1x1: chunk count padded to even
+    assert lib.sg3_modconv_packed_floats(81, 128, 3, _sg3abi.SG3_CONV_F16) == 81 * 8 * 9 * 16       # same packing as f16x3
 
 
 def test_gpu_tensor_without_library_raises(monkeypatch, tmp_path):
