@@ -52,7 +52,10 @@ class SEModule(Module):
         self.sigmoid = Sigmoid()
 
     def gate(self, x):
-        return self.sigmoid(self.fc2(self.relu(self.fc1(self.avg_pool(x)))))
+        # the two 1x1 convolutions act on a [N,C,1,1] tensor: plain matrix products
+        m = x.mean(dim=(2, 3))
+        m = torch.relu(m @ self.fc1.weight.flatten(1).t())
+        return torch.sigmoid(m @ self.fc2.weight.flatten(1).t()).unsqueeze(-1).unsqueeze(-1)
 
     def forward(self, x):
         return x * self.gate(x)

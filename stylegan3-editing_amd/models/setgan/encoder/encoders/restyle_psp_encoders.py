@@ -65,8 +65,16 @@ class BackboneEncoder(Module):
         w0 = torch.cat([s.convs[0].weight for s in self.styles], dim=0)
         b0 = torch.cat([s.convs[0].bias for s in self.styles], dim=0)
         pk['heads0'] = PackedConv(w0, bias=b0, act=ACT_LRELU, slope=slope, stride=2, padding=1)
-        pk['heads'] = [[PackedConv(s.convs[i].weight, bias=s.convs[i].bias, act=ACT_LRELU, slope=slope, stride=2, padding=1)
-                        for i in range(2, len(s.convs), 2)] for s in self.styles]
+        # the remaining head convolutions see 8x8, 4x4 and 2x2 maps: far too few pixels for an implicit-GEMM tile, and
+        # what bounds them is reading 16 x 9.4 MB of weights.  They run as ONE batched GEMM per level over all heads:
+        # [heads, N*pixels, 512*9] x [heads, 512*9, 512] on patches taken with unfold
+        n_levels = (len(self.styles[0].convs) // 2) - 1
+        pk['tail_w'] = [torch.stack([s.convs[2 * (l + 1)].weight.reshape(s.out_c, -1).t() for s in self.styles]).contiguous()
+                        for l in range(n_levels)]                                                       # [heads, I*9, O]
+        pk['tail_b'] = [torch.stack([s.convs[2 * (l + 1)].bias for s in self.styles]).unsqueeze(1) for l in range(n_levels)]
+        pk['lin_w'] = torch.stack([(s.linear.weight * s.linear.scale).t() for s in self.styles]).contiguous()   # [heads, in, out]
+        pk['lin_b'] = torch.stack([s.linear.bias * s.linear.lr_mul for s in self.styles]).unsqueeze(1)
+        pk['slope'] = float(self.styles[0].convs[1].negative_slope)
         self._packed = pk
 
     def _forward_hip(self, x):
@@ -76,14 +84,17 @@ class BackboneEncoder(Module):
         x = pk['stem'](x.float())
         for unit in self.body:
             x = unit.forward_hip(x)
-        h0 = pk['heads0'](x)                                   # [N, n_styles*512, 8, 8]
-        outs = []
-        for j, style in enumerate(self.styles):
-            h = h0[:, j * style.out_c:(j + 1) * style.out_c]
-            for conv in pk['heads'][j]:
-                h = conv(h)
-            outs.append(style.linear(h.reshape(-1, style.out_c)))
-        return self._combine(outs)
+        h = pk['heads0'](x)                                    # [N, heads*512, 8, 8]
+        n, heads, c = int(h.shape[0]), len(self.styles), self.styles[0].out_c
+        h = h.view(n, heads, c, h.shape[2], h.shape[3]).transpose(0, 1).reshape(heads * n, c, h.shape[2], h.shape[3])
+        for w, b in zip(pk['tail_w'], pk['tail_b']):
+            side = (int(h.shape[2]) + 1) // 2
+            cols = torch.nn.functional.unfold(h, kernel_size=3, padding=1, stride=2)               # [heads*N, C*9, side^2]
+            cols = cols.view(heads, n, c * 9, side * side).permute(0, 1, 3, 2).reshape(heads, n * side * side, c * 9)
+            h = torch.nn.functional.leaky_relu(torch.baddbmm(b, cols, w), pk['slope'])           # [heads, N*side^2, C]
+            h = h.view(heads, n, side, side, c).permute(0, 1, 4, 2, 3).reshape(heads * n, c, side, side)
+        codes = torch.baddbmm(pk['lin_b'], h.view(heads, n, c), pk['lin_w'])                       # EqualLinear of every head
+        return self._combine(list(codes.unbind(0)))
 
     def forward(self, x):
         if x.is_cuda and not self.training and not torch.is_grad_enabled():
