@@ -298,7 +298,7 @@ SG3_API int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream);
  * ---------------------------------------------------------------------- */
 typedef struct sg3_conv2d_params {
     const float*   x;          /* [N,I,H,W] */
-    const float*   wPacked;    /* sg3_modconv_packed_floats(O,I,k,SG3_CONV_FP32) floats */
+    const float*   wPacked;    /* sg3_modconv_packed_floats(O,I,k,precision) floats, written by sg3_conv2d_pack */
     const float*   inScale;    /* [I] or NULL */
     const float*   inShift;    /* [I] or NULL (NULL = 0) */
     const float*   bias;       /* [O] or NULL */
@@ -307,12 +307,15 @@ typedef struct sg3_conv2d_params {
     int32_t        N, I, O, H, W;
     int32_t        k, stride, pad;
     int32_t        act;
+    int32_t        precision;  /* SG3_CONV_FP32 (exact) | SG3_CONV_F16X3 (3x3, stride 1: fp16 x 3 split, fp32-equivalent) */
+    int32_t*       rangeFlag;  /* f16x3: device int, OR-ed with 1 when an operand left the fp16 range (the result of that
+                                * call is then invalid and the caller repeats it with SG3_CONV_FP32); never cleared here */
 } sg3_conv2d_params;
 
 SG3_API int sg3_conv2d(const sg3_conv2d_params* p, void* stream);
 
 /* w [O,I,k,k] (* outScale[o] when given: a folded BatchNorm) -> packed layout */
-SG3_API int sg3_conv2d_pack(const float* w, const float* outScale, float* wPacked, int O, int I, int k, void* stream);
+SG3_API int sg3_conv2d_pack(const float* w, const float* outScale, float* wPacked, int O, int I, int k, int precision, void* stream);
 
 #ifdef __cplusplus
 }

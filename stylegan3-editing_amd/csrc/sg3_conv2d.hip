@@ -9,6 +9,7 @@
 // precedes the first convolution of a bottleneck) applied while staging, only inside the image so zero padding stays
 // zero; epilogue bias (folded BatchNorm / conv bias) and PReLU / leaky ReLU.
 #include "sg3_common.h"
+#include "sg3_split.h"
 
 namespace sg3 {
 
@@ -176,6 +177,247 @@ conv2d_pack_kernel(const float* w, const float* outScale, float* wp, int O, int 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Split-precision form for the 3x3 stride-1 convolutions that carry the backbone's FLOPs (same arithmetic as
+// modconv_f16x3_kernel in sg3_modconv.hip: x = hi + lo in fp16, Ah*Bh + Ah*Bl + Al*Bh on v_mfma_f32_32x32x16_f16, fp32
+// accumulation, fp32-equivalent).  No bound on BatchNorm-ed activations is known ahead of time and none is needed for
+// accuracy (fp16's exponent range covers 6e-5 .. 65504 at full split precision, smaller magnitudes lose only bits that
+// are below 1e-11 absolute); what must not happen silently is overflow, so every workgroup tracks max |operand| while
+// staging and raises `*flag` when it exceeds the fp16 range -- the caller then repeats the layer stack on the exact
+// fp32 kernel (torch_utils/ops/plain_conv.py).  Weights are packed [O][I/16][tap][hi|lo][16] halfs by
+// conv2d_pack_f16x3_kernel with the folded BatchNorm scale applied before the split.
+template <int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(256, (TM * TN <= 4) ? 2 : 1)
+conv2d_f16x3_kernel(PlainConvParams p, int* flag) {
+    constexpr int KS = 3, TAPS = 9, KC = 16;
+    constexpr int BM = WM * TM * 32;
+    constexpr int ROWS = WN * TN;
+    constexpr int PH = ROWS + KS - 1, PW = 32 + KS - 1;
+    constexpr int NPIX = PH * PW;
+    constexpr int AS = TAPS * 32 + 8;
+    constexpr int AROW_V = TAPS * 32 / 8;
+    constexpr int TPR = (BM == 32) ? 8 : (BM == 64 ? 4 : 2);
+    constexpr int A_PER = (AROW_V + TPR - 1) / TPR;
+    constexpr int BPLANE = NPIX * 8;
+    constexpr int PX_PER = (NPIX + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(BM * TPR <= 256, "A staging map");
+
+    extern __shared__ __attribute__((aligned(16))) _Float16 smh[];
+    _Float16* sA = smh;
+    _Float16* sB = smh + BM * AS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    int bid = blockIdx.x;
+    {
+        const int nb = p.totalBlocks, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int mt = bid % p.mTiles; bid /= p.mTiles;
+    const int xt = bid % p.xTiles; bid /= p.xTiles;
+    const int yt = bid % p.yTiles; const int n = bid / p.yTiles;
+    const int o0 = mt * BM, x0 = xt * 32, y0 = yt * ROWS;
+
+    const unsigned HWb = (unsigned)(p.H * p.W) * 4u;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + (size_t)n * p.I * p.H * p.W), (short)0, (int)((unsigned)p.I * HWb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.wp, (short)0, (int)((unsigned)p.O * (unsigned)p.nch * (unsigned)(AROW_V * 16)), 0x00020000);
+    const int arow = tid / TPR, acol = tid % TPR;
+    const bool aOk = arow < BM;
+    const unsigned aG = (aOk && o0 + arow < p.O) ? ((unsigned)(o0 + arow) * (unsigned)p.nch * (AROW_V * 16) + acol * 16) : 0x80000000u;
+    _Float16* aL = sA + arow * AS + acol * 8;
+    unsigned bG[PX_PER];
+    int bL[PX_PER];
+    float bM[PX_PER];                       // 1 inside the image, 0 in the zero padding: the input affine applies to real pixels only
+#pragma unroll
+    for (int q = 0; q < PX_PER; q++) {
+        const int e = tid + 256 * q;
+        const int px = e % PW, py = e / PW;
+        const int gy = y0 - p.pad + py, gx = x0 - p.pad + px;
+        const bool ok = e < NPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        bG[q] = ok ? (unsigned)(gy * p.W + gx) * 4u : 0x80000000u;
+        bL[q] = e < NPIX ? e * 8 : -1;
+        bM[q] = ok ? 1.f : 0.f;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; a++)
+#pragma unroll
+        for (int b = 0; b < TN; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    u32x4 ra[A_PER];
+    float rb[PX_PER][2][8];
+    float peak = 0.f;
+
+    auto fetch = [&](int ch) {
+        const unsigned aoff = aG + (unsigned)ch * (AROW_V * 16);
+#pragma unroll
+        for (int q = 0; q < A_PER; q++) {
+            if (AROW_V % TPR == 0 || acol + q * TPR < AROW_V)
+                ra[q] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)(aoff + q * TPR * 16), 0, 0);
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int ci = ch * KC + hf * 8 + c;                        // wave-uniform
+                const bool cOk = ci < p.I;
+                const unsigned coff = cOk ? (unsigned)ci * HWb : 0u;
+                const float sc = cOk ? (p.inScale ? p.inScale[ci] : 1.f) : 0.f;
+                const float sh = (cOk && p.inScale && p.inShift) ? p.inShift[ci] : 0.f;
+#pragma unroll
+                for (int q = 0; q < PX_PER; q++) {
+                    const float v = __builtin_fmaf(bufld<float>::ld(xr, bG[q], coff), sc, sh * bM[q]);
+                    rb[q][hf][c] = v;
+                    peak = __builtin_fmaxf(peak, __builtin_fabsf(v));
+                }
+            }
+    };
+    auto stage = [&]() {
+        if (aOk) {
+#pragma unroll
+            for (int q = 0; q < A_PER; q++)
+                if (AROW_V % TPR == 0 || acol + q * TPR < AROW_V)
+                    *reinterpret_cast<u32x4*>(aL + q * TPR * 8) = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < PX_PER; q++) {
+            if (bL[q] < 0) continue;
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                v2h h[4], l[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) split2(rb[q][hf][2 * c], rb[q][hf][2 * c + 1], h[c], l[c]);
+                _Float16* dst = sB + (hf * 2) * BPLANE + bL[q];
+                *reinterpret_cast<v8h*>(dst) = __builtin_shufflevector(__builtin_shufflevector(h[0], h[1], 0, 1, 2, 3), __builtin_shufflevector(h[2], h[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
+                *reinterpret_cast<v8h*>(dst + BPLANE) = __builtin_shufflevector(__builtin_shufflevector(l[0], l[1], 0, 1, 2, 3), __builtin_shufflevector(l[2], l[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+    };
+    struct Frags { v8h ah[TM], al[TM], bh[TN], bl[TN]; };
+    auto load_frags = [&](Frags& f, int tap) {
+        const int ky = tap / KS, kx = tap % KS;
+#pragma unroll
+        for (int a = 0; a < TM; a++) {
+            const _Float16* src = sA + ((wm * TM + a) * 32 + li) * AS + tap * 32 + lh * 8;
+            f.ah[a] = *reinterpret_cast<const v8h*>(src);
+            f.al[a] = *reinterpret_cast<const v8h*>(src + 16);
+        }
+#pragma unroll
+        for (int b = 0; b < TN; b++) {
+            const _Float16* src = sB + (lh * 2) * BPLANE + ((wn * TN + b + ky) * PW + li + kx) * 8;
+            f.bh[b] = *reinterpret_cast<const v8h*>(src);
+            f.bl[b] = *reinterpret_cast<const v8h*>(src + BPLANE);
+        }
+    };
+    auto mfma_tap = [&](const Frags& f) {
+#pragma unroll
+        for (int a = 0; a < TM; a++)
+#pragma unroll
+            for (int b = 0; b < TN; b++) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[a], f.bh[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bl[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bh[b], acc[a][b], 0, 0, 0);
+            }
+    };
+
+    fetch(0);
+    for (int ch = 0; ch < p.nch; ch++) {
+        __syncthreads();
+        stage();
+        __syncthreads();
+        if (ch + 1 < p.nch) fetch(ch + 1);
+        Frags f0, f1;
+        load_frags(f0, 0);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; tap += 2) {
+            if (tap + 1 < TAPS) load_frags(f1, tap + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_tap(f0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < TAPS) {
+                if (tap + 2 < TAPS) load_frags(f0, tap + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tap(f1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // fp16 range check on the staged operands (NaN compares false and propagates to the output on its own)
+    if (peak > 65000.f) atomicOr(flag, 1);
+
+    float* outp = p.out + (size_t)n * p.O * p.outH * p.outW;
+    const int gx = x0 + li;
+#pragma unroll
+    for (int a = 0; a < TM; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int o = o0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (o >= p.O) continue;
+            const float bv = p.bias ? p.bias[o] : 0.f;
+            const float sl = p.act == 1 ? p.slope[o] : (p.act == 2 ? p.slope[0] : 1.f);
+#pragma unroll
+            for (int b = 0; b < TN; b++) {
+                const int gy = y0 + wn * TN + b;
+                if (gy < p.outH && gx < p.outW) {
+                    float v = acc[a][b][r] + bv;
+                    if (p.act) v = v < 0.f ? v * sl : v;
+                    outp[((size_t)o * p.outH + gy) * p.outW + gx] = v;
+                }
+            }
+        }
+}
+
+__global__ void __launch_bounds__(256)
+conv2d_pack_f16x3_kernel(const float* w, const float* outScale, float* wp, int O, int I, int nch) {
+    const int o = blockIdx.x;
+    const float sc = outScale ? outScale[o] : 1.f;
+    _Float16* dst = reinterpret_cast<_Float16*>(wp) + (size_t)o * nch * 9 * 32;
+    for (int j = threadIdx.x; j < nch * 9 * 16; j += 256) {
+        const int c = j % 16, t = (j / 16) % 9, ch = j / (16 * 9);
+        const int i = ch * 16 + c;
+        const float v = i < I ? w[((size_t)o * I + i) * 9 + t] * sc : 0.f;
+        const _Float16 h = (_Float16)v;
+        _Float16* d = dst + ((size_t)ch * 9 + t) * 32 + c;
+        d[0] = h;
+        d[16] = (_Float16)(v - (float)h);
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_plain_f16x3(const sg3_conv2d_params& q, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, ROWS = WN * TN;
+    constexpr size_t ldsBytes = ((size_t)BM * (9 * 32 + 8) + 4 * (size_t)(ROWS + 2) * 34 * 8) * sizeof(_Float16);
+    PlainConvParams p;
+    p.x = q.x; p.wp = q.wPacked; p.inScale = q.inScale; p.inShift = q.inShift; p.bias = q.bias; p.slope = q.slope; p.out = q.out;
+    p.N = q.N; p.I = q.I; p.O = q.O; p.H = q.H; p.W = q.W; p.stride = 1; p.pad = q.pad; p.act = q.act;
+    p.outH = q.H + 2 * q.pad - 2; p.outW = q.W + 2 * q.pad - 2;
+    p.nch = ceil_div(q.I, 16);
+    p.xTiles = ceil_div(p.outW, 32); p.yTiles = ceil_div(p.outH, ROWS); p.mTiles = ceil_div(q.O, BM);
+    const long long total = (long long)p.xTiles * p.yTiles * p.mTiles * q.N;
+    if (total > 0x7fffffffLL) { set_error("conv2d: grid too large"); return SG3_BAD_ARG; }
+    p.totalBlocks = (int)total;
+    auto kern = conv2d_f16x3_kernel<WM, WN, TM, TN>;
+    if (ldsBytes > 64 * 1024)
+        SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), ldsBytes, st, p, q.rangeFlag);
+    SG3_LAUNCH_CHECK("conv2d_f16x3_kernel");
+    return SG3_OK;
+}
+
+static int dispatch_plain_f16x3(const sg3_conv2d_params& q, hipStream_t st) {
+    const int outH = q.H + 2 * q.pad - 2;
+    if (outH <= 16) return launch_plain_f16x3<1, 4, 2, 1>(q, st);                 // 64 x (4 rows x 32): the 16x16 maps
+    return launch_plain_f16x3<1, 4, 2, 2>(q, st);                                 // 64 x (8 rows x 32)
+}
+
 template <int KS, int STRIDE, int WM, int WN, int TM, int TN>
 static int launch_plain(const sg3_conv2d_params& q, hipStream_t st) {
     constexpr int BM = WM * TM * 32, ROWS = WN * TN, KC = (KS == 3) ? 8 : 16;
@@ -206,9 +448,15 @@ static int dispatch_plain(const sg3_conv2d_params& q, hipStream_t st) {
 
 extern "C" {
 
-int sg3_conv2d_pack(const float* w, const float* outScale, float* wPacked, int O, int I, int k, void* stream) {
+int sg3_conv2d_pack(const float* w, const float* outScale, float* wPacked, int O, int I, int k, int precision, void* stream) {
     using namespace sg3;
     SG3_REQUIRE(w && wPacked && O > 0 && I > 0 && (k == 1 || k == 3), "conv2d_pack: bad arguments");
+    SG3_REQUIRE(precision == SG3_CONV_FP32 || (precision == SG3_CONV_F16X3 && k == 3), "conv2d_pack: f16x3 packing is for 3x3 kernels");
+    if (precision == SG3_CONV_F16X3) {
+        hipLaunchKernelGGL(conv2d_pack_f16x3_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, w, outScale, wPacked, O, I, ceil_div(I, 16));
+        SG3_LAUNCH_CHECK("conv2d_pack_f16x3_kernel");
+        return SG3_OK;
+    }
     const int kc = k == 3 ? 8 : 16;
     hipLaunchKernelGGL(conv2d_pack_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, w, outScale, wPacked, O, I, k * k, kc, ceil_div(I, kc));
     SG3_LAUNCH_CHECK("conv2d_pack_kernel");
@@ -226,6 +474,12 @@ int sg3_conv2d(const sg3_conv2d_params* p, void* stream) {
     SG3_REQUIRE(p->act == 0 || p->slope, "conv2d: slope missing");
     SG3_REQUIRE(p->H + 2 * p->pad >= p->k && p->W + 2 * p->pad >= p->k, "conv2d: empty output");
     hipStream_t st = (hipStream_t)stream;
+    if (p->precision == SG3_CONV_F16X3) {
+        SG3_REQUIRE(p->k == 3 && p->stride == 1 && p->rangeFlag, "conv2d: the f16x3 form takes 3x3 stride-1 kernels and a range flag");
+        SG3_REQUIRE((int64_t)p->I * p->H * p->W * 4 < (int64_t)1 << 31, "conv2d: f16x3 needs a sample below 2 GiB (32-bit offsets)");
+        return dispatch_plain_f16x3(*p, st);
+    }
+    SG3_REQUIRE(p->precision == SG3_CONV_FP32, "conv2d: bad precision");
     if (p->k == 3) return p->stride == 1 ? dispatch_plain<3, 1>(*p, st) : dispatch_plain<3, 2>(*p, st);
     return p->stride == 1 ? dispatch_plain<1, 1>(*p, st) : dispatch_plain<1, 2>(*p, st);
 }

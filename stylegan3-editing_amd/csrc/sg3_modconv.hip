@@ -22,6 +22,7 @@
 //
 // demodulation (dcoef) is applied in the epilogue; bias/activation belong to the following filtered_lrelu.
 #include "sg3_common.h"
+#include "sg3_split.h"
 
 namespace sg3 {
 
@@ -198,35 +199,6 @@ modconv_mfma_kernel(ConvParams p) {
 // so |x*sIn| < 2^15 given the caller's bound on |x| (dcoef carries the inverse power).
 // LDS image: A rows of 9 taps x (16 hi | 16 lo) halfs + 8 halfs of padding (conflict-free b128 rows); B as four
 // planes [channel-half][hi|lo][py][px][8 halfs], so a lane's im2col fragment for tap (ky,kx) is one ds_read_b128.
-typedef _Float16 v8h __attribute__((ext_vector_type(8)));
-typedef _Float16 v2h __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-template <typename T> struct bufld;
-template <> struct bufld<float> {
-    static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, (int)soff, 0));
-    }
-};
-template <> struct bufld<_Float16> {
-    static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
-        return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, (int)off, (int)soff, 0));
-    }
-};
-
-// x = hi + lo with hi = the top 11 significand bits of x (exactly representable in fp16 for normal-range values) and
-// lo = fp16(x - hi); two values per call, packed for the MFMA operand registers
-__device__ __forceinline__ v2h round2(float x0, float x1) {          // plain fp16 form: round to nearest even
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    return __builtin_convertvector((f2){x0, x1}, v2h);
-}
-__device__ __forceinline__ void split2(float x0, float x1, v2h& hi, v2h& lo) {
-    const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x0) & 0xffffe000u);
-    const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x1) & 0xffffe000u);
-    hi = __builtin_bit_cast(v2h, __builtin_amdgcn_cvt_pkrtz(h0, h1));
-    lo = __builtin_bit_cast(v2h, __builtin_amdgcn_cvt_pkrtz(x0 - h0, x1 - h1));
-}
-
 // SPLIT = false is the plain fp16 form (SG3_CONV_F16): operands rounded to fp16 once, ONE MFMA per K step -- the
 // arithmetic of the reference's fp16 layers (fp16 cuDNN convolution with fp32 accumulation).
 template <typename T, int WM, int WN, int TM, int TN, bool SPLIT>

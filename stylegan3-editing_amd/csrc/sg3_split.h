@@ -1,0 +1,36 @@
+// sg3_split.h -- operand handling shared by the split-precision (fp16 x 3) MFMA kernels.
+#pragma once
+#include "sg3_common.h"
+
+namespace sg3 {
+
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct bufld;
+template <> struct bufld<float> {
+    static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, (int)soff, 0));
+    }
+};
+template <> struct bufld<_Float16> {
+    static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+        return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, (int)off, (int)soff, 0));
+    }
+};
+
+// x = hi + lo with hi = the top 11 significand bits of x (exactly representable in fp16 for normal-range values) and
+// lo = fp16(x - hi); two values per call, packed for the MFMA operand registers
+__device__ __forceinline__ v2h round2(float x0, float x1) {          // plain fp16 form: round to nearest even
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    return __builtin_convertvector((f2){x0, x1}, v2h);
+}
+__device__ __forceinline__ void split2(float x0, float x1, v2h& hi, v2h& lo) {
+    const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x0) & 0xffffe000u);
+    const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x1) & 0xffffe000u);
+    hi = __builtin_bit_cast(v2h, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+    lo = __builtin_bit_cast(v2h, __builtin_amdgcn_cvt_pkrtz(x0 - h0, x1 - h1));
+}
+
+} // namespace sg3

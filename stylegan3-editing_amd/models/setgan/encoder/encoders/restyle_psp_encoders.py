@@ -60,14 +60,13 @@ class BackboneEncoder(Module):
         conv, bn, prelu = self.input_layer[0], self.input_layer[1], self.input_layer[2]
         a, b = bn_affine(bn)
         pk = dict(stem=PackedConv(conv.weight, out_scale=a, bias=b, act=ACT_PRELU, slope=prelu.weight, stride=1, padding=1))
-        slope = torch.tensor([self.styles[0].convs[1].negative_slope], dtype=torch.float32, device=conv.weight.device)
-        # first head convolution of every style block reads the same feature map: one convolution, n_styles*512 outputs
-        w0 = torch.cat([s.convs[0].weight for s in self.styles], dim=0)
-        b0 = torch.cat([s.convs[0].bias for s in self.styles], dim=0)
-        pk['heads0'] = PackedConv(w0, bias=b0, act=ACT_LRELU, slope=slope, stride=2, padding=1)
-        # the remaining head convolutions see 8x8, 4x4 and 2x2 maps: far too few pixels for an implicit-GEMM tile, and
-        # what bounds them is reading 16 x 9.4 MB of weights.  They run as ONE batched GEMM per level over all heads:
-        # [heads, N*pixels, 512*9] x [heads, 512*9, 512] on patches taken with unfold
+        # Head convolutions.  Every style block starts from the same [N,512,16,16] map and halves it to 8x8, 4x4, 2x2,
+        # 1x1: far too few pixels for an implicit-GEMM tile, and what bounds them is reading the weights (16 heads x 4
+        # levels x 9.4 MB).  They run as plain GEMMs on patches taken with unfold: the first level of all heads as ONE
+        # [N*64, 512*9] x [512*9, heads*512] product,
+        pk['head0_w'] = torch.cat([s.convs[0].weight.reshape(s.out_c, -1) for s in self.styles], dim=0).t().contiguous()   # [I*9, heads*O]
+        pk['head0_b'] = torch.cat([s.convs[0].bias for s in self.styles], dim=0).unsqueeze(0)
+        # the remaining levels as ONE batched GEMM per level over all heads: [heads, N*pixels, 512*9] x [heads, 512*9, 512]
         n_levels = (len(self.styles[0].convs) // 2) - 1
         pk['tail_w'] = [torch.stack([s.convs[2 * (l + 1)].weight.reshape(s.out_c, -1).t() for s in self.styles]).contiguous()
                         for l in range(n_levels)]                                                       # [heads, I*9, O]
@@ -78,15 +77,32 @@ class BackboneEncoder(Module):
         self._packed = pk
 
     def _forward_hip(self, x):
+        """Split-precision convolutions first; if any of them met an operand outside the fp16 range (flagged on the
+        device) the forward is repeated on the exact fp32 kernels."""
+        from torch_utils.ops import plain_conv
+        plain_conv.reset_overflow(x.device)
+        out = self._forward_kernels(x)
+        if plain_conv.precision != 'fp32' and plain_conv.overflowed(x.device):
+            saved, plain_conv.precision = plain_conv.precision, 'fp32'
+            try:
+                out = self._forward_kernels(x)
+            finally:
+                plain_conv.precision = saved
+        return out
+
+    def _forward_kernels(self, x):
         if self._packed is None:
             self._pack()
         pk = self._packed
         x = pk['stem'](x.float())
         for unit in self.body:
             x = unit.forward_hip(x)
-        h = pk['heads0'](x)                                    # [N, heads*512, 8, 8]
-        n, heads, c = int(h.shape[0]), len(self.styles), self.styles[0].out_c
-        h = h.view(n, heads, c, h.shape[2], h.shape[3]).transpose(0, 1).reshape(heads * n, c, h.shape[2], h.shape[3])
+        n, heads, c = int(x.shape[0]), len(self.styles), self.styles[0].out_c
+        side = (int(x.shape[2]) + 1) // 2
+        cols = torch.nn.functional.unfold(x, kernel_size=3, padding=1, stride=2)                      # [N, C*9, side^2]
+        cols = cols.permute(0, 2, 1).reshape(n * side * side, -1)
+        h = torch.nn.functional.leaky_relu(torch.addmm(pk['head0_b'], cols, pk['head0_w']), pk['slope'])   # [N*side^2, heads*C]
+        h = h.view(n, side, side, heads, c).permute(3, 0, 4, 1, 2).reshape(heads * n, c, side, side)
         for w, b in zip(pk['tail_w'], pk['tail_b']):
             side = (int(h.shape[2]) + 1) // 2
             cols = torch.nn.functional.unfold(h, kernel_size=3, padding=1, stride=2)               # [heads*N, C*9, side^2]

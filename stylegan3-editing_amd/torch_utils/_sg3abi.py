@@ -65,7 +65,7 @@ class ModconvPrepParams(ctypes.Structure):
 class Conv2dParams(ctypes.Structure):
     _fields_ = [('x', c_vp), ('wPacked', c_vp), ('inScale', c_vp), ('inShift', c_vp), ('bias', c_vp), ('slope', c_vp), ('out', c_vp),
                 ('N', c_i32), ('I', c_i32), ('O', c_i32), ('H', c_i32), ('W', c_i32), ('k', c_i32), ('stride', c_i32), ('pad', c_i32),
-                ('act', c_i32)]
+                ('act', c_i32), ('precision', c_i32), ('rangeFlag', c_vp)]
 
 
 # every symbol include/sg3_ops.h declares: (name, restype, argtypes)
@@ -84,7 +84,7 @@ EXPORTS = [
     ('sg3_modulated_conv2d', ctypes.c_int, [ctypes.POINTER(ModconvParams), c_vp]),
     ('sg3_modulated_conv2d_prep', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), c_vp]),
     ('sg3_conv2d', ctypes.c_int, [ctypes.POINTER(Conv2dParams), c_vp]),
-    ('sg3_conv2d_pack', ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp]),
+    ('sg3_conv2d_pack', ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp]),
 ]
 
 _lib = None

@@ -14,6 +14,31 @@ from .. import _sg3abi as abi
 
 ACT_NONE, ACT_PRELU, ACT_LRELU = 0, 1, 2
 
+# Arithmetic of the 3x3 stride-1 convolutions (the bulk of the backbone):
+#   'f16x3' : fp16 hi/lo operand split, three fp16 MFMAs per K step, fp32 accumulation (fp32-equivalent, 5.3x the fp32 MFMA
+#             rate).  Operands must stay inside the fp16 range; every launch checks that on the device and raises a flag
+#             (`overflowed`), on which the caller repeats its forward with 'fp32'.
+#   'fp32'  : v_mfma_f32_32x32x2_f32, exact products.
+precision = 'f16x3'
+_flags = {}
+
+
+def _flag(device):
+    key = (device.type, device.index)
+    if key not in _flags:
+        _flags[key] = torch.zeros([1], dtype=torch.int32, device=device)
+    return _flags[key]
+
+
+def reset_overflow(device):
+    _flag(torch.device(device)).zero_()
+
+
+def overflowed(device):
+    """True when a split-precision launch since the last `reset_overflow` met an operand outside the fp16 range
+    (synchronises with the device)."""
+    return bool(int(_flag(torch.device(device)).item()))
+
 
 class PackedConv:
     """Weights of one convolution in the implicit-GEMM operand layout, plus its fused epilogue / prologue vectors."""
@@ -23,14 +48,22 @@ class PackedConv:
         self.O, self.I, self.k = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
         assert self.k in (1, 3) and stride in (1, 2)
         self.stride, self.padding, self.act = int(stride), int(padding), int(act)
-        lib = abi.load()
         dev = weight.device
-        self.packed = torch.empty([int(lib.sg3_modconv_packed_floats(self.O, self.I, self.k, abi.SG3_CONV_FP32))], dtype=torch.float32, device=dev)
-        w = weight.detach().contiguous()
+        self._w = weight.detach().contiguous()
         f32 = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
         self.out_scale, self.bias, self.in_scale, self.in_shift, self.slope = f32(out_scale), f32(bias), f32(in_scale), f32(in_shift), f32(slope)
-        with torch.cuda.device(dev):
-            abi.check(lib.sg3_conv2d_pack(abi.ptr(w), abi.ptr(self.out_scale), abi.ptr(self.packed), self.O, self.I, self.k, abi.stream_ptr(dev)), 'sg3_conv2d_pack')
+        self._packed = {}
+
+    def packed(self, prec):
+        """Packed operand image for one arithmetic form (built on first use)."""
+        if prec not in self._packed:
+            lib = abi.load()
+            dev = self._w.device
+            buf = torch.empty([int(lib.sg3_modconv_packed_floats(self.O, self.I, self.k, prec))], dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                abi.check(lib.sg3_conv2d_pack(abi.ptr(self._w), abi.ptr(self.out_scale), abi.ptr(buf), self.O, self.I, self.k, prec, abi.stream_ptr(dev)), 'sg3_conv2d_pack')
+            self._packed[prec] = buf
+        return self._packed[prec]
 
     def __call__(self, x):
         assert x.is_cuda and x.dtype == torch.float32 and x.ndim == 4 and x.shape[1] == self.I
@@ -39,8 +72,11 @@ class PackedConv:
         oh = (h + 2 * self.padding - self.k) // self.stride + 1
         ow = (w + 2 * self.padding - self.k) // self.stride + 1
         out = torch.empty([n, self.O, oh, ow], dtype=torch.float32, device=x.device)
+        split = precision == 'f16x3' and self.k == 3 and self.stride == 1
+        prec = abi.SG3_CONV_F16X3 if split else abi.SG3_CONV_FP32
         p = abi.Conv2dParams()
-        p.x, p.wPacked, p.out = abi.ptr(x), abi.ptr(self.packed), abi.ptr(out)
+        p.x, p.wPacked, p.out = abi.ptr(x), abi.ptr(self.packed(prec)), abi.ptr(out)
+        p.precision, p.rangeFlag = prec, (abi.ptr(_flag(x.device)) if split else None)
         p.inScale, p.inShift, p.bias, p.slope = abi.ptr(self.in_scale), abi.ptr(self.in_shift), abi.ptr(self.bias), abi.ptr(self.slope)
         p.N, p.I, p.O, p.H, p.W = n, self.I, self.O, h, w
         p.k, p.stride, p.pad, p.act = self.k, self.stride, self.padding, self.act

@@ -40,6 +40,7 @@ def run_on_batch(inputs, net, opts, avg_image, landmarks_transform=None):
     results_batch = {idx: [] for idx in range(inputs.shape[0])}
     results_latent = {idx: [] for idx in range(inputs.shape[0])}
     y_hat, latent = None, None
+    step_latents = []
     resize_outputs = getattr(opts, 'resize_outputs', False)
     for it in range(opts.n_iters_per_batch):
         if it == 0:
@@ -57,6 +58,11 @@ def run_on_batch(inputs, net, opts, avg_image, landmarks_transform=None):
             y_hat, _, latent = res
         for idx in range(inputs.shape[0]):
             results_batch[idx].append(y_hat[idx])
-            results_latent[idx].append(latent[idx].cpu().numpy())
+        step_latents.append(latent)
         y_hat = net.face_pool(y_hat)
+    # one device -> host copy for all steps (the reference copies every sample of every step as it goes, which
+    # drains the GPU queue 16 x 5 times per batch)
+    all_latents = torch.stack(step_latents).cpu().numpy()               # [steps, N, 16, 512]
+    for idx in range(inputs.shape[0]):
+        results_latent[idx] = [all_latents[it, idx] for it in range(len(step_latents))]
     return results_batch, results_latent

@@ -65,3 +65,47 @@ def test_backbone_encoder():
         enc.invalidate_packed()
         assert maxabs(enc(x).cpu().numpy(), enc._forward_torch(x).cpu().numpy()) <= 2e-3
         assert maxabs(enc(x).cpu().numpy(), g['codes']) > 1e-3
+
+
+def test_split_precision_range_guard():
+    """The split-precision convolution flags operands outside the fp16 range on the device; the encoder then repeats its
+    forward on the exact fp32 kernels, so huge activations still give the fp32 result."""
+    from torch_utils.ops import plain_conv
+    from torch_utils.ops.plain_conv import PackedConv
+    from oracle import oracle as O
+    from golden_cases import rand
+    T = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(DEV)  # noqa: E731
+    w = rand(31, 32, 16, 3, 3) * 0.2
+    conv = PackedConv(T(w), stride=1, padding=1)
+    x = rand(32, 1, 16, 20, 40)
+    plain_conv.reset_overflow(DEV)
+    y = conv(T(x))
+    assert not plain_conv.overflowed(DEV)
+    assert maxabs(y.cpu().numpy(), O.conv2d(x, w, None, 1, 1)) <= 2e-5
+    conv(T(x * 1e5))
+    assert plain_conv.overflowed(DEV)                       # |x| ~ 4e5 > 65504
+    plain_conv.reset_overflow(DEV)
+    assert not plain_conv.overflowed(DEV)
+    saved, plain_conv.precision = plain_conv.precision, 'fp32'
+    try:
+        y32 = conv(T(x * 1e5))
+    finally:
+        plain_conv.precision = saved
+    ref = O.conv2d((x * 1e5).astype(np.float32), w, None, 1, 1)
+    assert maxabs(y32.cpu().numpy(), ref) <= 2e-5 * float(np.abs(ref).max())
+    # end to end: an encoder fed 1e6-scale inputs falls back and still matches its own fp32 run
+    from models.setgan.encoder.encoders.restyle_psp_encoders import BackboneEncoder
+    from synth_weights import synth_encoder_state_dict
+    enc = BackboneEncoder(50, 'ir_se', 4)
+    man = {k: list(v.shape) for k, v in enc.state_dict().items()}
+    enc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth_encoder_state_dict(man, seed=0).items()})
+    enc = enc.eval().requires_grad_(False).to(DEV)
+    xin = T(rand(33, 1, 6, 256, 256) * 1e6)
+    with torch.no_grad():
+        a = enc(xin)
+        plain_conv.precision = 'fp32'
+        try:
+            b = enc(xin)
+        finally:
+            plain_conv.precision = saved
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
