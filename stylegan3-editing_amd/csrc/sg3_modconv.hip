@@ -201,9 +201,15 @@ modconv_mfma_kernel(ConvParams p) {
 // planes [channel-half][hi|lo][py][px][8 halfs], so a lane's im2col fragment for tap (ky,kx) is one ds_read_b128.
 // SPLIT = false is the plain fp16 form (SG3_CONV_F16): operands rounded to fp16 once, ONE MFMA per K step -- the
 // arithmetic of the reference's fp16 layers (fp16 cuDNN convolution with fp32 accumulation).
-template <typename T, int WM, int WN, int TM, int TN, bool SPLIT>
+// ROWSTREAM selects the MFMA loop order.  false: tap by tap, every tap reading its own A and B fragments (2 TM + 2 TN
+// ds_read_b128 per 3 TM TN MFMAs).  true (TM == 1): column offset kx outermost, the three A fragments of that column
+// held in registers while the patch rows stream through: one B fragment serves up to three output rows (ky = 0..2), so
+// a wave issues 18 + 6 (TN + 2) reads per 27 TN MFMAs -- 0.5 per MFMA at TN = 4 against 0.67 / 1.0 for the 2x2 / 1x2
+// tap-by-tap tiles.  LDS bandwidth, not the matrix cores, bounds the tap-by-tap form.
+template <typename T, int WM, int WN, int TM, int TN, bool SPLIT, bool ROWSTREAM>
 __global__ void __launch_bounds__(256, (TM * TN <= 4) ? 2 : 1)      // two workgroups per CU whenever the accumulators allow
 modconv_f16x3_kernel(ConvParams p) {
+    static_assert(!ROWSTREAM || TM == 1, "row streaming keeps one M block per wave");
     constexpr int KS = 3, TAPS = 9, KC = 16;
     constexpr int NPART = SPLIT ? 2 : 1;               // B planes per channel half: hi | lo
     constexpr int BM = WM * TM * 32;
@@ -355,19 +361,65 @@ modconv_f16x3_kernel(ConvParams p) {
         stage();
         __syncthreads();
         if (ch + 1 < p.nch) fetch(ch + 1);
-        Frags f0, f1;
-        load_frags(f0, 0);
+        if (ROWSTREAM) {
+            struct BFrag { v8h h, l; };
+            auto load_b = [&](BFrag& f, int pr, int kx) {
+                const _Float16* src = sB + (lh * NPART) * BPLANE + ((wn * TN + pr) * PW + li + kx) * 8;
+                f.h = *reinterpret_cast<const v8h*>(src);
+                if (SPLIT) f.l = *reinterpret_cast<const v8h*>(src + BPLANE);
+            };
+            auto mfma_row = [&](const BFrag& f, const v8h (&ah)[3], const v8h (&al)[3], int pr) {
+                // the three products go round the (up to three) output rows this patch row feeds, so consecutive
+                // MFMAs never wait on each other's accumulator
+                if (SPLIT) {
 #pragma unroll
-        for (int tap = 0; tap < TAPS; tap += 2) {
-            if (tap + 1 < TAPS) load_frags(f1, tap + 1);
-            __builtin_amdgcn_sched_barrier(0);          // keep the next tap's ds_reads ahead of this tap's MFMAs
-            mfma_tap(f0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (tap + 1 < TAPS) {
-                if (tap + 2 < TAPS) load_frags(f0, tap + 2);
+                    for (int ky = 0; ky < 3; ky++) { const int b = pr - ky; if (b >= 0 && b < TN) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ky], f.h, acc[0][b], 0, 0, 0); }
+#pragma unroll
+                    for (int ky = 0; ky < 3; ky++) { const int b = pr - ky; if (b >= 0 && b < TN) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ky], f.l, acc[0][b], 0, 0, 0); }
+                }
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++) { const int b = pr - ky; if (b >= 0 && b < TN) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ky], f.h, acc[0][b], 0, 0, 0); }
+            };
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                v8h ah[3], al[3];
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++) {
+                    const _Float16* src = sA + (wm * 32 + li) * AS + (ky * 3 + kx) * 32 + lh * 8;
+                    ah[ky] = *reinterpret_cast<const v8h*>(src);
+                    if (SPLIT) al[ky] = *reinterpret_cast<const v8h*>(src + 16);
+                }
+                BFrag b0, b1;
+                load_b(b0, 0, kx);
+#pragma unroll
+                for (int pr = 0; pr < TN + 2; pr += 2) {
+                    if (pr + 1 < TN + 2) load_b(b1, pr + 1, kx);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_row(b0, ah, al, pr);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pr + 1 < TN + 2) {
+                        if (pr + 2 < TN + 2) load_b(b0, pr + 2, kx);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_row(b1, ah, al, pr + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        } else {
+            Frags f0, f1;
+            load_frags(f0, 0);
+#pragma unroll
+            for (int tap = 0; tap < TAPS; tap += 2) {
+                if (tap + 1 < TAPS) load_frags(f1, tap + 1);
+                __builtin_amdgcn_sched_barrier(0);          // keep the next tap's ds_reads ahead of this tap's MFMAs
+                mfma_tap(f0);
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_tap(f1);
-                __builtin_amdgcn_sched_barrier(0);
+                if (tap + 1 < TAPS) {
+                    if (tap + 2 < TAPS) load_frags(f0, tap + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_tap(f1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
@@ -767,7 +819,7 @@ static int dispatch_conv(const sg3_modconv_params& q, hipStream_t st) {
     }
 }
 
-template <typename T, int WM, int WN, int TM, int TN, bool SPLIT>
+template <typename T, int WM, int WN, int TM, int TN, bool SPLIT, bool ROWSTREAM>
 static int launch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     constexpr int BM = WM * TM * 32, ROWS = WN * TN;
     constexpr int PH = ROWS + 2, PW = 34;
@@ -781,7 +833,7 @@ static int launch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     const long long total = (long long)p.xTiles * p.yTiles * p.mTiles * q.N;
     if (total > 0x7fffffffLL) { set_error("modulated_conv2d: grid too large"); return SG3_BAD_ARG; }
     p.totalBlocks = (int)total;
-    auto kern = modconv_f16x3_kernel<T, WM, WN, TM, TN, SPLIT>;
+    auto kern = modconv_f16x3_kernel<T, WM, WN, TM, TN, SPLIT, ROWSTREAM>;
     if (ldsBytes > 64 * 1024)
         SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), ldsBytes, st, p);
@@ -793,10 +845,10 @@ template <typename T, bool SPLIT>
 static int dispatch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     const int O = q.O;
     // two workgroups per CU (<= 80 KB LDS each) so one stages while the other runs its MFMAs
-    if (O <= 32) return launch_conv_f16x3<T, 1, 4, 1, 2, SPLIT>(q, st);             //  32 x (8 rows x 32)
+    if (O <= 32) return launch_conv_f16x3<T, 1, 4, 1, 4, SPLIT, true>(q, st);       //  32 x (16 rows x 32), row streaming
     const int t64 = ceil_div(O, 64) * 64, t96 = ceil_div(O, 96) * 96;
-    if (t96 < t64) return launch_conv_f16x3<T, 1, 4, 3, 2, SPLIT>(q, st);           //  96 x (8 rows x 32)
-    return launch_conv_f16x3<T, 1, 4, 2, 2, SPLIT>(q, st);                          //  64 x (8 rows x 32)
+    if (t96 < t64) return launch_conv_f16x3<T, 1, 4, 3, 2, SPLIT, false>(q, st);    //  96 x (8 rows x 32)
+    return launch_conv_f16x3<T, 2, 2, 1, 4, SPLIT, true>(q, st);                    //  64 x (8 rows x 32), row streaming
 }
 
 template <typename T, int WM, int WN, int TM, int TN, bool SPLIT>
