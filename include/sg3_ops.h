@@ -76,7 +76,7 @@ SG3_API int         sg3_device_count(void);
 typedef struct sg3_filtered_lrelu_params {
     const void*    x;          /* [N,C,xH,xW] */
     void*          y;          /* [N,C,yH,yW] */
-    const void*    b;          /* [C] bias, same dtype as x (never NULL; caller passes zeros) */
+    const void*    b;          /* [C] bias, same dtype as x, or NULL (no bias) */
     uint8_t*       s;          /* sign tensor or NULL */
     const float*   fu;         /* upsampling taps */
     const float*   fd;         /* downsampling taps */
@@ -279,6 +279,34 @@ typedef struct sg3_modconv_params {
 } sg3_modconv_params;
 
 SG3_API int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream);
+
+/* ------------------------------------------------------------------------
+ * conv2d_wgrad -- per-sample weight gradient of the (modulated) convolution, the part of the backward of
+ *   models/stylegan3/networks_stylegan3.py:59-62 (grouped F.conv2d) that PTI needs
+ *   (inversion/scripts/run_pti_images.py:130-139):
+ *
+ *   dW[n,o,i,ky,kx] = sum_{y,x} dy[n,o,y,x] * x[n,i,y+ky-pad,x+kx-pad]
+ *
+ * The pixel (K) dimension is split over nBands x nSegGroups workgroup sets (sg3_conv2d_wgrad_splits proposes the
+ * counts); each writes its partial sum to partial[band*nSegGroups+group][n][tap][o][i] and the caller adds them up
+ * (deterministic; no float atomics).  Operands are multiplied by *scaleX / *scaleDy (device scalars, powers of two chosen
+ * by the caller so that the scaled magnitudes peak near 2^15: fp16 hi/lo split inside) and the result by 1/(scaleX*scaleDy).
+ * ---------------------------------------------------------------------- */
+typedef struct sg3_wgrad_params {
+    const void*    x;          /* [N,I,H,W] */
+    const void*    dy;         /* [N,O,OH,OW], OH = H + 2*pad - k + 1 */
+    float*         partial;    /* [nBands*nSegGroups, N, k*k, O, I] */
+    const float*   scaleX;     /* device scalar */
+    const float*   scaleDy;    /* device scalar */
+    int32_t        dtype;      /* SG3_F32 | SG3_F16 (x and dy) */
+    int32_t        N, I, O, H, W;
+    int32_t        k;          /* 1 or 3 */
+    int32_t        pad;
+    int32_t        nBands, nSegGroups;
+} sg3_wgrad_params;
+
+SG3_API int sg3_conv2d_wgrad_splits(int N, int I, int O, int H, int W, int k, int pad, int* nBands, int* nSegGroups);
+SG3_API int sg3_conv2d_wgrad(const sg3_wgrad_params* p, void* stream);
 
 /* ------------------------------------------------------------------------
  * conv2d -- the plain convolutions of the ReStyle encoder (IR-SE50 backbone and

@@ -62,6 +62,12 @@ class ModconvPrepParams(ctypes.Structure):
                 ('xBoundDev', c_vp)]
 
 
+class WgradParams(ctypes.Structure):
+    _fields_ = [('x', c_vp), ('dy', c_vp), ('partial', c_vp), ('scaleX', c_vp), ('scaleDy', c_vp), ('dtype', c_i32),
+                ('N', c_i32), ('I', c_i32), ('O', c_i32), ('H', c_i32), ('W', c_i32), ('k', c_i32), ('pad', c_i32),
+                ('nBands', c_i32), ('nSegGroups', c_i32)]
+
+
 class Conv2dParams(ctypes.Structure):
     _fields_ = [('x', c_vp), ('wPacked', c_vp), ('inScale', c_vp), ('inShift', c_vp), ('bias', c_vp), ('slope', c_vp), ('out', c_vp),
                 ('N', c_i32), ('I', c_i32), ('O', c_i32), ('H', c_i32), ('W', c_i32), ('k', c_i32), ('stride', c_i32), ('pad', c_i32),
@@ -84,6 +90,8 @@ EXPORTS = [
     ('sg3_modulated_conv2d', ctypes.c_int, [ctypes.POINTER(ModconvParams), c_vp]),
     ('sg3_modulated_conv2d_prep', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), c_vp]),
     ('sg3_conv2d', ctypes.c_int, [ctypes.POINTER(Conv2dParams), c_vp]),
+    ('sg3_conv2d_wgrad_splits', ctypes.c_int, [ctypes.c_int] * 7 + [ctypes.POINTER(ctypes.c_int)] * 2),
+    ('sg3_conv2d_wgrad', ctypes.c_int, [ctypes.POINTER(WgradParams), c_vp]),
     ('sg3_conv2d_pack', ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp]),
 ]
 

@@ -138,6 +138,33 @@ def _data_gradient(dy, w, s_in, dcoef, demodulate, padding):
     return dx
 
 
+def _pow2_scale(t):
+    """Device scalar 2^-e with e = ceil(log2(max|t| / 2^15)): brings the peak magnitude just below 2^15 (fp16 split range)."""
+    amax = t.detach().abs().amax().to(torch.float32).clamp_min(1e-30)
+    return torch.exp2(-torch.ceil(torch.log2(amax / 32768.0))).reshape(1)
+
+
+def _weight_gradient(x, dy, k, padding):
+    """dW[n,o,i,ky,kx] = sum_pixels dy[n,o] * x[n,i] (shifted): the per-sample weight gradient on the matrix cores
+    (csrc/sg3_wgrad.hip).  The pixel dimension is split over workgroups; the partial sums are added here."""
+    lib = abi.load()
+    x = x.contiguous(); dy = dy.contiguous()
+    n, ci, h, w = (int(v) for v in x.shape)
+    co = int(dy.shape[1])
+    nb, ng = ctypes.c_int(), ctypes.c_int()
+    abi.check(lib.sg3_conv2d_wgrad_splits(n, ci, co, h, w, k, int(padding), ctypes.byref(nb), ctypes.byref(ng)), 'sg3_conv2d_wgrad_splits')
+    partial = torch.empty([nb.value * ng.value, n, k * k, co, ci], dtype=torch.float32, device=x.device)
+    sx, sd = _pow2_scale(x), _pow2_scale(dy)
+    p = abi.WgradParams()
+    p.x, p.dy, p.partial, p.scaleX, p.scaleDy = abi.ptr(x), abi.ptr(dy), abi.ptr(partial), abi.ptr(sx), abi.ptr(sd)
+    p.dtype = abi.dtype_code(x.dtype)
+    p.N, p.I, p.O, p.H, p.W, p.k, p.pad = n, ci, co, h, w, int(k), int(padding)
+    p.nBands, p.nSegGroups = nb.value, ng.value
+    with torch.cuda.device(x.device):
+        abi.check(lib.sg3_conv2d_wgrad(ctypes.byref(p), abi.stream_ptr(x.device)), 'sg3_conv2d_wgrad')
+    return partial.sum(dim=0).permute(0, 2, 3, 1).reshape(n, co, ci, k, k)
+
+
 class _ModulatedConv2dHip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, s, input_gain, demodulate, padding, x_bound):  # pylint: disable=arguments-differ
@@ -173,21 +200,18 @@ class _ModulatedConv2dHip(torch.autograd.Function):
         if need[0]:
             out[0] = _data_gradient(dy, w, s_in, dcoef if dcoef.numel() else None, demodulate, padding)
         if need[1] or need[2] or (has_gain and need[3]):
-            # gradient of the per-sample effective weights (a grouped weight-gradient convolution), then the chain rule
+            # gradient of the per-sample effective weights (weight-gradient kernel), then the chain rule
             # through the small [N,O,I,k,k] tensor for w, s and input_gain
             with torch.enable_grad():
                 wd = w.detach().requires_grad_(need[1]); sd = s.detach().requires_grad_(need[2])
                 gd = g.detach().requires_grad_(need[3]) if has_gain else None
                 w_eff = _effective_weights(wd.float(), sd.float(), demodulate, gd, n)
-            wv = w_eff.detach().reshape(n * co, ci, k, k).to(x.dtype)
-            _, dw_eff, _ = torch.ops.aten.convolution_backward(
-                dy.reshape(1, n * co, *dy.shape[2:]), x.reshape(1, n * ci, *x.shape[2:]), wv, None,
-                [1, 1], [padding, padding], [1, 1], False, [0, 0], n, [False, True, False])
+            dw_eff = _weight_gradient(x, dy, k, padding)
             ins, idx = [], []
             for j, t in ((1, wd), (2, sd), (3, gd)):
                 if t is not None and need[j]:
                     ins.append(t); idx.append(j)
-            grads = torch.autograd.grad(w_eff, ins, dw_eff.reshape_as(w_eff).to(w_eff.dtype), allow_unused=True)
+            grads = torch.autograd.grad(w_eff, ins, dw_eff.to(w_eff.dtype), allow_unused=True)
             for j, gr in zip(idx, grads):
                 out[j] = gr
         return tuple(out)

@@ -370,6 +370,33 @@ def test_modulated_conv2d_fp16_form(n, ci, co, h, k):
     assert maxabs(y32.float().cpu().numpy(), ref) <= 1e-3 * scale                   # exact products: only the fp16 output rounding
 
 
+@pytest.mark.parametrize('n,ci,co,h,w,k,pad', [(2, 70, 100, 21, 37, 3, 2), (1, 32, 32, 70, 45, 3, 2), (1, 130, 64, 40, 40, 3, 1), (2, 64, 3, 33, 50, 1, 0),
+                                              (1, 200, 161, 30, 30, 1, 0), (1, 16, 16, 150, 150, 3, 2)])
+def test_conv2d_wgrad_kernel(n, ci, co, h, w, k, pad):
+    """Per-sample weight gradient kernel against the fp64 definition dW[n,o,i,ky,kx] = sum dy[n,o,y,x] xpad[n,i,y+ky,x+kx];
+    operands of very different magnitude (activations O(100), gradients O(1e-6)) exercise the power-of-two scaling."""
+    from torch_utils.ops import modulated_conv as mc
+    x = (rand(101, n, ci, h, w) * 60).astype(np.float32)
+    oh, ow = h + 2 * pad - k + 1, w + 2 * pad - k + 1
+    dy = (rand(102, n, co, oh, ow) * 3e-6).astype(np.float32)
+    got = mc._weight_gradient(T(x), T(dy), k, pad).cpu().numpy()
+    xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+    ref = np.zeros((n, co, ci, k, k))
+    for ky in range(k):
+        for kx in range(k):
+            ref[:, :, :, ky, kx] = np.einsum('noyx,niyx->noi', dy.astype(np.float64), xp[:, :, ky:ky + oh, kx:kx + ow])
+    assert got.shape == ref.shape
+    assert maxabs(got, ref) <= 3e-6 * float(np.abs(ref).max()), (maxabs(got, ref), float(np.abs(ref).max()))
+    # fp16 tensors
+    goth = mc._weight_gradient(T(x.astype(np.float16)), T((dy * 1e4).astype(np.float16)), k, pad).float().cpu().numpy()
+    xh = np.pad(x.astype(np.float16).astype(np.float64), ((0, 0), (0, 0), (pad, pad), (pad, pad))); dh = (dy * 1e4).astype(np.float16).astype(np.float64)
+    refh = np.zeros_like(ref)
+    for ky in range(k):
+        for kx in range(k):
+            refh[:, :, :, ky, kx] = np.einsum('noyx,niyx->noi', dh, xh[:, :, ky:ky + oh, kx:kx + ow])
+    assert maxabs(goth, refh) <= 3e-6 * float(np.abs(refh).max())
+
+
 def test_modulated_conv2d_fp16_and_grad():
     from oracle import oracle as O
     from models.stylegan3.networks_stylegan3 import modulated_conv2d
