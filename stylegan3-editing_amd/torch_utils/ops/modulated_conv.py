@@ -122,7 +122,7 @@ def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None, x_bound_dev=
     return out, s_in, dcoef
 
 
-def _data_gradient(dy, w, s_in, dcoef, demodulate, padding):
+def _data_gradient(dy, w, s_in, dcoef, demodulate, padding, dy_amax=None):
     """dx of the modulated convolution on the same implicit-GEMM kernels: with out = d * conv(wn, x * sIn),
     dx = sIn * conv(flip(wn)^T, dy * d) with padding k-1-pad -- the forward kernel with the roles of the two per-sample
     scale vectors exchanged.  The bound the split-precision path needs is max |dy|, taken on the device."""
@@ -133,18 +133,22 @@ def _data_gradient(dy, w, s_in, dcoef, demodulate, padding):
         wn = wn * wn.square().mean([1, 2, 3], keepdim=True).rsqrt()
     wt = wn.flip([2, 3]).transpose(0, 1).contiguous()                         # [I,O,k,k]
     mod = dcoef if dcoef is not None else torch.ones([n, co], dtype=torch.float32, device=dy.device)
-    bound = dy.detach().abs().amax().to(torch.float32).reshape(1)
+    bound = dy_amax if dy_amax is not None else _amax(dy)
     dx, _, _ = _launch(dy, wt, mod, False, k - 1 - padding, None, x_bound_dev=bound, out_scale=s_in)
     return dx
 
 
-def _pow2_scale(t):
-    """Device scalar 2^-e with e = ceil(log2(max|t| / 2^15)): brings the peak magnitude just below 2^15 (fp16 split range)."""
-    amax = t.detach().abs().amax().to(torch.float32).clamp_min(1e-30)
-    return torch.exp2(-torch.ceil(torch.log2(amax / 32768.0))).reshape(1)
+def _amax(t):
+    """max |t| as a one-element device tensor, in one reduction pass (no |t| temporary)."""
+    return torch.linalg.vector_norm(t.detach().reshape(-1), ord=float('inf')).to(torch.float32).reshape(1)
 
 
-def _weight_gradient(x, dy, k, padding):
+def _pow2_scale(amax):
+    """Device scalar 2^-e with e = ceil(log2(amax / 2^15)): brings the peak magnitude just below 2^15 (fp16 split range)."""
+    return torch.exp2(-torch.ceil(torch.log2(amax.clamp_min(1e-30) / 32768.0)))
+
+
+def _weight_gradient(x, dy, k, padding, x_amax=None, dy_amax=None):
     """dW[n,o,i,ky,kx] = sum_pixels dy[n,o] * x[n,i] (shifted): the per-sample weight gradient on the matrix cores
     (csrc/sg3_wgrad.hip).  The pixel dimension is split over workgroups; the partial sums are added here."""
     lib = abi.load()
@@ -154,7 +158,8 @@ def _weight_gradient(x, dy, k, padding):
     nb, ng = ctypes.c_int(), ctypes.c_int()
     abi.check(lib.sg3_conv2d_wgrad_splits(n, ci, co, h, w, k, int(padding), ctypes.byref(nb), ctypes.byref(ng)), 'sg3_conv2d_wgrad_splits')
     partial = torch.empty([nb.value * ng.value, n, k * k, co, ci], dtype=torch.float32, device=x.device)
-    sx, sd = _pow2_scale(x), _pow2_scale(dy)
+    sx = _pow2_scale(x_amax if x_amax is not None else _amax(x))
+    sd = _pow2_scale(dy_amax if dy_amax is not None else _amax(dy))
     p = abi.WgradParams()
     p.x, p.dy, p.partial, p.scaleX, p.scaleDy = abi.ptr(x), abi.ptr(dy), abi.ptr(partial), abi.ptr(sx), abi.ptr(sd)
     p.dtype = abi.dtype_code(x.dtype)
@@ -172,6 +177,7 @@ class _ModulatedConv2dHip(torch.autograd.Function):
         ctx.save_for_backward(x, w, s, input_gain if input_gain is not None else torch.empty(0), s_in,
                               dcoef if dcoef is not None else torch.empty(0))
         ctx.cfg = (demodulate, padding, input_gain is not None)
+        ctx.x_bound = x_bound
         return out
 
     @staticmethod
@@ -195,10 +201,11 @@ class _ModulatedConv2dHip(torch.autograd.Function):
                 out[j] = gr
             return tuple(out)
         dy = dy.contiguous()
+        dy_amax = _amax(dy)                                   # shared by both gradient kernels' operand scaling
         n = int(x.shape[0])
         co, ci, k, _ = (int(v) for v in w.shape)
         if need[0]:
-            out[0] = _data_gradient(dy, w, s_in, dcoef if dcoef.numel() else None, demodulate, padding)
+            out[0] = _data_gradient(dy, w, s_in, dcoef if dcoef.numel() else None, demodulate, padding, dy_amax=dy_amax)
         if need[1] or need[2] or (has_gain and need[3]):
             # gradient of the per-sample effective weights (weight-gradient kernel), then the chain rule
             # through the small [N,O,I,k,k] tensor for w, s and input_gain
@@ -206,7 +213,10 @@ class _ModulatedConv2dHip(torch.autograd.Function):
                 wd = w.detach().requires_grad_(need[1]); sd = s.detach().requires_grad_(need[2])
                 gd = g.detach().requires_grad_(need[3]) if has_gain else None
                 w_eff = _effective_weights(wd.float(), sd.float(), demodulate, gd, n)
-            dw_eff = _weight_gradient(x, dy, k, padding)
+            x_amax = None
+            if ctx.x_bound is not None and ctx.x_bound > 0:
+                x_amax = torch.full([1], float(ctx.x_bound), dtype=torch.float32, device=x.device)     # the layer's own bound: no pass over x
+            dw_eff = _weight_gradient(x, dy, k, padding, x_amax=x_amax, dy_amax=dy_amax)
             ins, idx = [], []
             for j, t in ((1, wd), (2, sd), (3, gd)):
                 if t is not None and need[j]:
