@@ -149,6 +149,34 @@ def bench_inversion(G, device, rank, world, frames_per_gpu=16, restyle_steps=5, 
                          'all-gather of [F,16,512] latents; synthetic weights')
 
 
+def bench_pti_step(device, steps=4):
+    """One pivotal-tuning step (reference run_pti_images.py:126-139): fp32 synthesis forward with sign write, MSE, backward
+    through the fused adjoint / gradient kernels, Adam over the synthesis weights; batch 1, FFHQ-1024 config T."""
+    from synth_weights import synth_ws
+    G = build_generator('T1024', device)
+    G.requires_grad_(True)
+    opt = torch.optim.Adam(list(G.synthesis.parameters())[3:], lr=3e-4)
+    w = torch.from_numpy(synth_ws(1, G.num_ws, G.w_dim, seed=3)).to(device)
+    target = torch.zeros(1, 3, G.img_resolution, G.img_resolution, device=device)
+
+    def step():
+        out = G.synthesis(w, noise_mode='const', force_fp32=True)
+        loss = torch.nn.functional.mse_loss(out, target)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    del G, opt
+    torch.cuda.empty_cache()
+    return {'steps_per_s': 1.0 / dt, 'ms_per_step': dt * 1e3, 'batch': 1}
+
+
 def bench_extras(G, ws, device, steps=5):
     """Secondary single-GPU measurements (eager launches, not the headline): the reference's default mixed-precision
     execution of the same workload, and config R (1x1 convolutions, radial down filters) at 1024 and 512."""
@@ -168,6 +196,7 @@ def bench_extras(G, ws, device, steps=5):
 
     G.synthesis.input.transform = torch.eye(3, device=device)     # the inversion measurement leaves per-frame transforms behind
     out = {'T1024_mixed_fp16': run(G, ws)}
+    out['T1024_pti_step'] = bench_pti_step(device)
     for cfg, batch in (('R1024', 4), ('R512', 8)):
         gen = build_generator(cfg, device)
         w = torch.from_numpy(synth_ws(batch, gen.num_ws, gen.w_dim, seed=1)).to(device)

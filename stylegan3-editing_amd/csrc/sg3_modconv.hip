@@ -730,7 +730,8 @@ modconv_prep_w_kernel(sg3_modconv_prep_params p, int kc, int nch) {
     }
 }
 
-// prep B: one workgroup per sample: normalise styles over the WHOLE batch, write sIn and dcoef
+// prep B: gridDim.y workgroups per sample: normalise styles over the WHOLE batch, write sIn (first workgroup) and this
+// workgroup's share of dcoef (one output channel per wave at a time: coalesced rows of wsq, shuffle reduction)
 __global__ void __launch_bounds__(256)
 modconv_prep_s_kernel(sg3_modconv_prep_params p) {
     __shared__ float red[256];
@@ -770,16 +771,20 @@ modconv_prep_s_kernel(sg3_modconv_prep_params p) {
         down = ldexpf(1.f, -e); up = ldexpf(1.f, e);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < p.I; i += 256) p.sIn[(size_t)n * p.I + i] = s2[p.I + i] * down;
+    if (blockIdx.y == 0)
+        for (int i = threadIdx.x; i < p.I; i += 256) p.sIn[(size_t)n * p.I + i] = s2[p.I + i] * down;
     if (p.demodulate) {
-        for (int o = threadIdx.x; o < p.O; o += 256) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int o = blockIdx.y * 4 + wave; o < p.O; o += gridDim.y * 4) {
             const float* wq = p.wsq + (size_t)o * p.I;
             float s = 0.f;
-            for (int i = 0; i < p.I; i++) s += wq[i] * s2[i];
-            p.dcoef[(size_t)n * p.O + o] = rsqrtf(s + 1e-8f) * up;
+            for (int i = lane; i < p.I; i += 64) s += wq[i] * s2[i];
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+            if (lane == 0) p.dcoef[(size_t)n * p.O + o] = rsqrtf(s + 1e-8f) * up;
         }
     } else if (p.precision != SG3_CONV_FP32) {
-        for (int o = threadIdx.x; o < p.O; o += 256) p.dcoef[(size_t)n * p.O + o] = up;
+        for (int o = blockIdx.y * 256 + threadIdx.x; o < p.O; o += gridDim.y * 256) p.dcoef[(size_t)n * p.O + o] = up;
     }
 }
 
@@ -910,7 +915,7 @@ int sg3_modulated_conv2d_prep(const sg3_modconv_prep_params* p, void* stream) {
     const int nch = p->precision != SG3_CONV_FP32 ? f16x3_chunks(p->I, p->k) : ceil_div(p->I, kc);
     hipLaunchKernelGGL(modconv_prep_w_kernel, dim3(p->O), dim3(256), 0, st, *p, kc, nch);
     SG3_LAUNCH_CHECK("modconv_prep_w_kernel");
-    hipLaunchKernelGGL(modconv_prep_s_kernel, dim3(p->N), dim3(256), (size_t)p->I * 2 * sizeof(float), st, *p);
+    hipLaunchKernelGGL(modconv_prep_s_kernel, dim3(p->N, min(16, ceil_div(p->O, 32))), dim3(256), (size_t)p->I * 2 * sizeof(float), st, *p);
     SG3_LAUNCH_CHECK("modconv_prep_s_kernel");
     return SG3_OK;
 }
