@@ -294,12 +294,21 @@ modconv_f16x3_kernel(ConvParams p) {
                 // channel offset rides in the scalar offset (not range checked: padded channels alias channel 0 and
                 // are multiplied by zero); the pixel offset is the range-checked vector offset
                 const unsigned coff = ci < p.I ? (unsigned)ci * HWb : 0u;
-                const float sc = ci < p.I ? sInN[ci] : 0.f;                  // scalar load
+                // NO arithmetic on the loaded values here: a use would put the s_waitcnt for these loads in front of
+                // the MFMA loop and expose the memory latency every chunk; the style scale is applied in stage()
 #pragma unroll
-                for (int q = 0; q < PX_PER; q++) rb[q][hf][c] = bufld<T>::ld(xr, bG[q], coff) * sc;
+                for (int q = 0; q < PX_PER; q++) rb[q][hf][c] = bufld<T>::ld(xr, bG[q], coff);
             }
     };
-    auto stage = [&]() {
+    auto stage = [&](int ch) {
+        float sc[2][8];
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int ci = ch * KC + hf * 8 + c;
+                sc[hf][c] = ci < p.I ? sInN[ci] : 0.f;                       // scalar loads; padded channels are multiplied by zero
+            }
         if (aOk) {
 #pragma unroll
             for (int q = 0; q < A_PER; q++)
@@ -314,8 +323,9 @@ modconv_f16x3_kernel(ConvParams p) {
                 v2h h[4], l[4];
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    if (SPLIT) split2(rb[q][hf][2 * c], rb[q][hf][2 * c + 1], h[c], l[c]);
-                    else h[c] = round2(rb[q][hf][2 * c], rb[q][hf][2 * c + 1]);
+                    const float v0 = rb[q][hf][2 * c] * sc[hf][2 * c], v1 = rb[q][hf][2 * c + 1] * sc[hf][2 * c + 1];
+                    if (SPLIT) split2(v0, v1, h[c], l[c]);
+                    else h[c] = round2(v0, v1);
                 }
                 _Float16* dst = sB + (hf * NPART) * BPLANE + bL[q];
                 *reinterpret_cast<v8h*>(dst) = __builtin_shufflevector(__builtin_shufflevector(h[0], h[1], 0, 1, 2, 3), __builtin_shufflevector(h[2], h[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
@@ -358,7 +368,7 @@ modconv_f16x3_kernel(ConvParams p) {
     fetch(0);
     for (int ch = 0; ch < p.nch; ch++) {
         __syncthreads();
-        stage();
+        stage(ch);
         __syncthreads();
         if (ch + 1 < p.nch) fetch(ch + 1);
         if (ROWSTREAM) {
