@@ -480,7 +480,8 @@ modconv1_f16x3_kernel(ConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
-    const int kh = wave >> 2;                          // channel half (of each 16) this thread stages: wave-uniform
+    // staging task of this thread: a PAIR of adjacent pixels x the 8 channels of one (k-step, channel-half); wave-uniform group
+    const int ssub = wave >> 2, kh = (wave >> 1) & 1;
 
     int bid = blockIdx.x;
     {
@@ -490,7 +491,10 @@ modconv1_f16x3_kernel(ConvParams p) {
     const int mt = bid % p.mTiles; bid /= p.mTiles;
     const int xt = bid % p.xTiles; bid /= p.xTiles;
     const int yt = bid % p.yTiles; const int n = bid / p.yTiles;
-    const int o0 = mt * BM, x0 = xt * 32, y0 = yt * ROWS;
+    // a 1x1 kernel has no halo, so the 256 pixels of a tile are a FLAT run of the H*W plane: every channel contributes
+    // one contiguous 1 KB run (8-byte loads, full cache lines) instead of 8 row segments of 128 bytes
+    const int P = p.H * p.W;
+    const int o0 = mt * BM, p0 = (yt * p.xTiles + xt) * NPIX;
 
     const unsigned HWb = (unsigned)(p.H * p.W) * (unsigned)sizeof(T);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
@@ -506,13 +510,9 @@ modconv1_f16x3_kernel(ConvParams p) {
         aG[q] = ok ? ((unsigned)(o0 + row) * (unsigned)p.nch * (AROW_V * 16) + col * 16) : 0x80000000u;
         aL[q] = v < A_VEC ? row * AS + col * 8 : -1;
     }
-    // B: this thread's patch pixel
-    const int e = tid & 255;
-    unsigned bG;
-    {
-        const int px = e & 31, py = e >> 5, gy = y0 + py, gx = x0 + px;
-        bG = (gy < p.H && gx < p.W) ? (unsigned)(gy * p.W + gx) * (unsigned)sizeof(T) : 0x80000000u;
-    }
+    // B: this thread's pixel pair (pairs beyond the plane read the next channel or zero: those columns are never stored)
+    const int e2 = tid & 127;
+    const unsigned bG = (p0 + 2 * e2 < P) ? (unsigned)(p0 + 2 * e2) * (unsigned)sizeof(T) : 0x80000000u;
     const float* sInN = p.sIn + (size_t)n * p.I;
 
     f32x16 acc[TM][TN];
@@ -524,37 +524,43 @@ modconv1_f16x3_kernel(ConvParams p) {
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
     u32x4 ra[A_PER];
-    float rb[KSUB][8];
+    typename bufld<T>::raw2 rb[8];                     // raw pixel pairs, one per channel (unpacked in stage)
 
     auto fetch = [&](int ch) {
 #pragma unroll
         for (int q = 0; q < A_PER; q++)
             ra[q] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)(aG[q] + (unsigned)ch * (AROW_V * 16)), 0, 0);
 #pragma unroll
-        for (int sub = 0; sub < KSUB; sub++)
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const int ci = ch * KC + sub * 16 + kh * 8 + c;                 // wave-uniform
-                const unsigned coff = ci < p.I ? (unsigned)ci * HWb : 0u;
-                const float sc = ci < p.I ? sInN[ci] : 0.f;
-                rb[sub][c] = bufld<T>::ld(xr, bG, coff) * sc;
-            }
+        for (int c = 0; c < 8; c++) {
+            const int ci = ch * KC + ssub * 16 + kh * 8 + c;                    // wave-uniform
+            const unsigned coff = ci < p.I ? (unsigned)ci * HWb : 0u;
+            rb[c] = bufld<T>::ld2(xr, bG, coff);       // no use of the values here: their s_waitcnt belongs after the MFMAs
+        }
     };
-    auto stage = [&](_Float16* buf) {
+    auto stage = [&](_Float16* buf, int ch) {
         _Float16* sA = buf;
         _Float16* sB = buf + BM * AS;
+        float rv[8][2];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int ci = ch * KC + ssub * 16 + kh * 8 + c;
+            const float sc = ci < p.I ? sInN[ci] : 0.f;        // scalar load; padded channels are multiplied by zero
+            float v0, v1;
+            bufld<T>::unpack2(rb[c], v0, v1);
+            rv[c][0] = v0 * sc; rv[c][1] = v1 * sc;
+        }
 #pragma unroll
         for (int q = 0; q < A_PER; q++)
             if (aL[q] >= 0) *reinterpret_cast<u32x4*>(sA + aL[q]) = ra[q];
 #pragma unroll
-        for (int sub = 0; sub < KSUB; sub++) {
+        for (int j = 0; j < 2; j++) {
             v2h h[4], l[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                if (SPLIT) split2(rb[sub][2 * c], rb[sub][2 * c + 1], h[c], l[c]);
-                else h[c] = round2(rb[sub][2 * c], rb[sub][2 * c + 1]);
+                if (SPLIT) split2(rv[2 * c][j], rv[2 * c + 1][j], h[c], l[c]);
+                else h[c] = round2(rv[2 * c][j], rv[2 * c + 1][j]);
             }
-            _Float16* dst = sB + ((sub * 2 + kh) * NPART) * BPLANE + e * 8;
+            _Float16* dst = sB + ((ssub * 2 + kh) * NPART) * BPLANE + (2 * e2 + j) * 8;
             *reinterpret_cast<v8h*>(dst) = __builtin_shufflevector(__builtin_shufflevector(h[0], h[1], 0, 1, 2, 3), __builtin_shufflevector(h[2], h[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
             if (SPLIT)
                 *reinterpret_cast<v8h*>(dst + BPLANE) = __builtin_shufflevector(__builtin_shufflevector(l[0], l[1], 0, 1, 2, 3), __builtin_shufflevector(l[2], l[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
@@ -591,7 +597,7 @@ modconv1_f16x3_kernel(ConvParams p) {
     };
 
     fetch(0);
-    stage(smh);
+    stage(smh, 0);
     __syncthreads();
     for (int ch = 0; ch < p.nch; ch++) {
         const _Float16* cur = smh + (ch & 1) * BUF;
@@ -604,12 +610,11 @@ modconv1_f16x3_kernel(ConvParams p) {
         mfma_step(f0);
         mfma_step(f1);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) stage(smh + ((ch + 1) & 1) * BUF);       // the other buffer: its readers passed the previous barrier
+        if (more) stage(smh + ((ch + 1) & 1) * BUF, ch + 1);       // the other buffer: its readers passed the previous barrier
         __syncthreads();
     }
 
-    T* outp = (T*)p.out + (size_t)n * p.O * p.outH * p.outW;
-    const int gx = x0 + li;
+    T* outp = (T*)p.out + (size_t)n * p.O * P;
 #pragma unroll
     for (int a = 0; a < TM; a++)
 #pragma unroll
@@ -619,9 +624,8 @@ modconv1_f16x3_kernel(ConvParams p) {
             const float d = p.dcoef[(size_t)n * p.O + o];
 #pragma unroll
             for (int b = 0; b < TN; b++) {
-                const int gy = y0 + wn * TN + b;
-                if (gy < p.outH && gx < p.outW)
-                    io<T>::st(outp + ((size_t)o * p.outH + gy) * p.outW + gx, acc[a][b][r] * d);
+                const int px = p0 + (wn * TN + b) * 32 + li;
+                if (px < P) io<T>::st(outp + (size_t)o * P + px, acc[a][b][r] * d);
             }
         }
 }
@@ -875,7 +879,7 @@ static int launch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     p.N = q.N; p.I = q.I; p.O = q.O; p.H = q.H; p.W = q.W; p.pad = 0;
     p.outH = q.H; p.outW = q.W;
     p.nch = f16x3_chunks(q.I, 1) / 2;                  // stages of 32 channels
-    p.xTiles = ceil_div(p.outW, 32); p.yTiles = ceil_div(p.outH, ROWS); p.mTiles = ceil_div(q.O, BM);
+    p.xTiles = ceil_div(q.H * q.W, ROWS * 32); p.yTiles = 1; p.mTiles = ceil_div(q.O, BM);     // flat 256-pixel tiles
     const long long total = (long long)p.xTiles * p.yTiles * p.mTiles * q.N;
     if (total > 0x7fffffffLL) { set_error("modulated_conv2d: grid too large"); return SG3_BAD_ARG; }
     p.totalBlocks = (int)total;
@@ -942,6 +946,7 @@ int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream) {
     if (p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16) {
         SG3_REQUIRE(p->dcoef, "modulated_conv2d: f16x3 needs dcoef");
         SG3_REQUIRE(p->k == 3 || p->pad == 0, "modulated_conv2d: f16x3 1x1 kernels take no padding");
+        SG3_REQUIRE(p->k == 3 || ((p->H * p->W) & 1) == 0, "modulated_conv2d: f16x3 1x1 kernels need an even number of pixels (pair loads)");
         SG3_REQUIRE((int64_t)p->I * p->H * p->W * 4 < (int64_t)1 << 31, "modulated_conv2d: f16x3 needs a sample below 2 GiB (32-bit offsets)");
         if (p->precision == SG3_CONV_F16) {
             if (p->k == 1) return p->dtype == SG3_F32 ? dispatch_conv1_f16x3<float, false>(*p, st) : dispatch_conv1_f16x3<_Float16, false>(*p, st);

@@ -13,10 +13,29 @@ template <> struct bufld<float> {
     static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, (int)soff, 0));
     }
+    // Two adjacent elements with one load, kept RAW (raw2) until the caller needs them (unpack2).
+    // NOTE: the elements are copied to scalars before __builtin_bit_cast: hipcc 7.2 (clang 22.0.0git roc-7.2.0) compiles
+    // __builtin_bit_cast(float, v.y) on an ext-vector element expression as a read of element 0.
+    typedef unsigned raw2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ raw2 ld2(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+        return __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, (int)soff, 0);
+    }
+    static __device__ __forceinline__ void unpack2(raw2 v, float& a, float& b) {
+        const unsigned lo = v.x, hi = v.y;
+        a = __builtin_bit_cast(float, lo); b = __builtin_bit_cast(float, hi);
+    }
 };
 template <> struct bufld<_Float16> {
     static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
         return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, (int)off, (int)soff, 0));
+    }
+    typedef unsigned raw2;
+    static __device__ __forceinline__ raw2 ld2(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+        return __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, (int)soff, 0);
+    }
+    static __device__ __forceinline__ void unpack2(raw2 v, float& a, float& b) {
+        const v2h h = __builtin_bit_cast(v2h, v);
+        a = (float)h.x; b = (float)h.y;
     }
 };
 

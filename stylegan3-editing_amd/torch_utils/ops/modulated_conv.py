@@ -92,7 +92,8 @@ def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None, x_bound_dev=
     if x.dtype == torch.float16 and x_bound is None and x_bound_dev is None:
         x_bound = 65504.0                                   # the dtype's own range
     bounded = x_bound_dev is not None or (x_bound is not None and x_bound > 0)
-    split = precision == 'f16x3' and (k == 3 or (padding == 0 and co > 4)) and bounded   # ToRGB (O <= 4) is HBM-bound: plain kernel
+    # 1x1: ToRGB (O <= 4) is HBM-bound and has its own kernel; the GEMM kernel loads pixel pairs (even plane size)
+    split = precision == 'f16x3' and (k == 3 or (padding == 0 and co > 4 and (h * wd) % 2 == 0)) and bounded
     prec = (abi.SG3_CONV_F16 if x.dtype == torch.float16 else abi.SG3_CONV_F16X3) if split else abi.SG3_CONV_FP32
     wn = torch.empty([int(lib.sg3_modconv_packed_floats(co, ci, k, prec))], dtype=torch.float32, device=dev)
     wsq = torch.empty([co, ci], dtype=torch.float32, device=dev)
