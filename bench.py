@@ -112,7 +112,7 @@ def cpu_baseline(cfg):
                 sample=f'1 image, {cfg} synthesis forward fp32, {dt:.1f} s on {O.num_threads()} OpenMP threads')
 
 
-def bench_inversion(G, device, rank, world, frames_per_gpu=16, restyle_steps=5, reps=2):
+def bench_inversion(G, device, rank, world, frames_per_gpu=16, restyle_steps=5, reps=2, decoder='T-1024'):
     """Secondary measurement (BASELINE metric, second half): ReStyle-pSp inversion frames/s.  Every rank inverts its own
     contiguous range of synthetic 256x256 frames (IR-SE50 encoder with seeded synthetic weights -> 5 refinement steps,
     each one encoder forward + one FFHQ-1024 synthesis forward), then the final latents are all-gathered (RCCL)."""
@@ -145,8 +145,8 @@ def bench_inversion(G, device, rank, world, frames_per_gpu=16, restyle_steps=5, 
     assert tuple(lat.shape) == (n_frames, 16, 512) and bool(torch.isfinite(lat).all())
     return dict(metric='ReStyle-pSp video-inversion frames/sec', value=n_frames * reps / float(t.item()), unit='frames/s',
                 frames_per_gpu=frames_per_gpu, restyle_steps=restyle_steps, scaling='weak',
-                workload='IR-SE50 encoder + FFHQ-1024 config-T decoder, 5 ReStyle steps per frame, frames sharded over ranks, '
-                         'all-gather of [F,16,512] latents; synthetic weights')
+                workload=f'IR-SE50 encoder + FFHQ-1024 config-{decoder} decoder (fp32), 5 ReStyle steps per frame, frames sharded over '
+                         'ranks, all-gather of [F,16,512] latents; synthetic weights')
 
 
 def bench_pti_step(device, steps=4):
@@ -289,9 +289,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    inversion = None
+    inversion = inversion_t = None
     if not args.no_inversion and args.config == 'T1024':
-        inversion = bench_inversion(G, device, rank, world)
+        # the reference's default decoder is config R (models/stylegan3/model.py:42-54); the config-T
+        # decoder of the headline workload is measured beside it
+        G_r = build_generator('R1024', device)
+        inversion = bench_inversion(G_r, device, rank, world, decoder='R-1024')
+        del G_r
+        torch.cuda.empty_cache()
+        inversion_t = bench_inversion(G, device, rank, world, decoder='T-1024')
     extras = None
     if not args.no_extras and world == 1 and args.config == 'T1024':
         extras = bench_extras(G, ws, device)
@@ -327,6 +333,7 @@ def main():
                         'peak_fp32_mfma_tflops': 157.3, 'kernel_ms_per_step': conv_ms},
         }
         out['inversion'] = inversion
+        out['inversion_T1024'] = inversion_t
         out['extras'] = extras
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.config)
