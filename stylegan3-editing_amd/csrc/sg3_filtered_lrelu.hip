@@ -439,7 +439,7 @@ struct Stream {
 
     static __device__ __forceinline__ void run(const StreamParams& p) {
         static_assert((D == 2 || D == 4) && (6 * U) % D == 0, "streaming kernel: down is 2 or 4");
-        static_assert(RADIAL == 0 || (D == 2 && SIGNS == 0), "radial variant: plain forward, down 2");
+        static_assert(RADIAL == 0 || (D == 2 && SIGNS != 2), "radial variant: forward passes (plain or sign-writing), down 2");
         __shared__ __attribute__((aligned(16))) float lds[Cfg::SIN + Cfg::SOUT];
         lds_f* sIn = (lds_f*)lds;
         lds_f* sOut = (lds_f*)lds + Cfg::SIN;                               // row exchanged for the horizontal down pass
@@ -594,7 +594,8 @@ static bool stream_supported(int up, int down, int fuW, int fuH, int fdW, int fd
 static bool stream_params_ok(const sg3_filtered_lrelu_params& q) {
     if (q.fdH != 0 && ((uintptr_t)q.fd & 15) != 0) return false;  // radial taps are fetched as 16-byte scalar quads
     const bool signs = q.writeSigns || q.readSigns;
-    if (signs && (q.fdH != 0 || !q.s || q.sH <= 0 || q.sWbytes <= 0)) return false;      // sign modes: separable filters only
+    if (signs && (!q.s || q.sH <= 0 || q.sWbytes <= 0)) return false;
+    if (q.readSigns && q.fdH != 0) return false;                                          // adjoint passes: separable down filter
     if (q.readSigns && q.up != 2) return false;                                            // adjoint passes upsample by 2
     if (q.down == 4 && !q.readSigns) return false;                                         // down 4 exists for the adjoint only
     return q.slope >= 0.f && q.slope <= 1.f && q.xStride[3] == 1 && q.yStride[3] == 1 && !(q.clamp < 0.f);
@@ -647,7 +648,12 @@ static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
             default: SG3_STREAM_LAUNCH(2, 4, 3, 0, 2); break;
         }
     } else if (q.writeSigns) {
-        if (q.up == 2) SG3_STREAM_LAUNCH_V(2, 0, 1); else SG3_STREAM_LAUNCH_V(4, 0, 1);
+        const int variant = q.fdH == 0 ? 0 : (q.flip ? 2 : 1);
+        if (q.up == 2) {
+            if (variant == 0) SG3_STREAM_LAUNCH_V(2, 0, 1); else if (variant == 1) SG3_STREAM_LAUNCH_V(2, 1, 1); else SG3_STREAM_LAUNCH_V(2, 2, 1);
+        } else {
+            if (variant == 0) SG3_STREAM_LAUNCH_V(4, 0, 1); else if (variant == 1) SG3_STREAM_LAUNCH_V(4, 1, 1); else SG3_STREAM_LAUNCH_V(4, 2, 1);
+        }
     } else {
         const int variant = q.fdH == 0 ? 0 : (q.flip ? 2 : 1);     // separable | radial | radial with flipped taps
         if (q.up == 2) {
