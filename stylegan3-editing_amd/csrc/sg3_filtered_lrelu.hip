@@ -130,6 +130,27 @@ __device__ __forceinline__ v2f radial_mul(v2f a, v2f tq) {
     return r;
 }
 
+// 2-D UP filter (the adjoint of the radial layers: their 12x12 down filter becomes the up filter).  acc += x * (tap pair),
+// x = one half of a register pair of adjacent input samples broadcast to both result lanes, the tap pair = one SGPR pair
+// of a filter row, halves exchanged when SWAP (filter row stored in the opposite order).
+template <int XHALF, bool SWAP>
+__device__ __forceinline__ v2f fma_x_tap(v2f xpair, v2f tapPair, v2f acc) {
+    v2f r;
+    if (XHALF == 0 && !SWAP) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(xpair), "s"(tapPair), "v"(acc));
+    if (XHALF == 1 && !SWAP) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(xpair), "s"(tapPair), "v"(acc));
+    if (XHALF == 0 && SWAP)  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(xpair), "s"(tapPair), "v"(acc));
+    if (XHALF == 1 && SWAP)  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(xpair), "s"(tapPair), "v"(acc));
+    return r;
+}
+// taps (G[k][2s+1], G[k][2s]) of the correlation-form filter row held in `t` (memory row k with flip, 11-k without):
+// memory pair s with the halves exchanged (flip), memory pair 5-s as it stands (no flip)
+template <bool FLIP>
+__device__ __forceinline__ v2f up2d_pair(const TapRow& t, int s) {
+    const int j = FLIP ? s : 5 - s;
+    const v4f v = j < 2 ? t.a : (j < 4 ? t.b : t.c);
+    return (j & 1) ? (v2f){v.z, v.w} : (v2f){v.x, v.y};
+}
+
 template <int U, int D> struct StreamCfg {
     static constexpr int FU = 6 * U, FD = 6 * D;
     static constexpr int CPL = 4;                       // upsampled columns per lane
@@ -173,6 +194,7 @@ template <typename T, int U, int D>
 struct WaveState {
     typedef StreamCfg<U, D> Cfg;
     v2f w[6][2];                  // sliding window of H-upsampled rows: [slot][column pair]
+    v2f xw[6][4];                 // 2-D up filter: sliding window of RAW input rows, 8 samples per lane as adjacent pairs
     v2f acc[6][2];                // output rows in flight: [slot][column pair]
     float pre[6][Cfg::NL];        // prefetched input samples (+bias) for the next 6 rows
     float bcol[Cfg::NL];          // bias where this lane's input column exists, else 0
@@ -222,6 +244,8 @@ struct Stream {
     static __device__ __forceinline__ void step(State& st, const StreamParams& p, const T* __restrict__ plane, T* __restrict__ oplane,
                                                 unsigned char* __restrict__ splane, lds_f* sIn, lds_f* sOut, int i, int delta, int lane,
                                                 int oy0, int oy1, int ox0, int oxN, bool pairStore) {
+        constexpr bool RDOWN = RADIAL == 1 || RADIAL == 2;        // full 12x12 DOWN filter (config R forward)
+        constexpr bool UP2D = RADIAL >= 3;                         // full 12x12 UP filter (adjoint of those layers)
         // ---- input row -> LDS -> this lane's H-upsampled samples ----
         wave_lds_sync();                 // the previous row's sIn reads precede this row's writes
 #pragma unroll
@@ -236,9 +260,9 @@ struct Stream {
             // volatile: keeps four ds_read_b64 (2 LDS cycles each); merged into ds_read2_b64 they run at a quarter of that
             const volatile lds_v2f* src = reinterpret_cast<const volatile lds_v2f*>(sIn + 2 * lane);
 #pragma unroll
-            for (int q = 0; q < 4; q++) { v2f t = src[q]; xs[2 * q] = t.x; xs[2 * q + 1] = t.y; }
+            for (int q = 0; q < 4; q++) { v2f t = src[q]; xs[2 * q] = t.x; xs[2 * q + 1] = t.y; if (UP2D) st.xw[S][q] = t; }
 #pragma unroll
-            for (int g = 0; g < 2; g++) {
+            for (int g = 0; g < 2 && !UP2D; g++) {
                 v2f a = splat(xs[g]) * st.tuP[0];
 #pragma unroll
                 for (int t = 1; t < 6; t++) a = fma2(splat(xs[g + t]), st.tuP[t], a);
@@ -258,13 +282,38 @@ struct Stream {
         }
         // ---- U new upsampled rows ----
         const float slope = p.slope, clampv = p.clamp / p.gain, gain = p.gain;
-        const float gainOut = (SIGNS == 1) ? 1.f : p.gain;      // sign-write mode applies the gain before the nonlinearity
+        // sign-write mode applies the gain before the nonlinearity; the 2-D up filter's taps carry no up^2 factor
+        const float gainOut = (SIGNS == 1) ? 1.f : (UP2D ? p.gain * (float)(U * U) : p.gain);
 #pragma unroll
         for (int j = 0; j < U; j++) {
             const int kv = U - 1 - j;                          // vertical up phase of this row
             v2f u0, u1;
+            if (UP2D) {
+                // 36 taps per upsampled sample: filter rows kv, kv + 2, .. against the six raw rows of the window; the rows
+                // stream through the scalar cache like the radial down filter's, the next one loading under this one's FMAs
+                constexpr bool FLIPU = RADIAL == 4;
+                u0 = splat(0.f); u1 = splat(0.f);
+                TapRow rowA, rowB;
+                radial_row_issue(rowA, p.fu, FLIPU ? kv : 11 - kv);
 #pragma unroll
-            for (int t = 0; t < 6; t++) {
+                for (int t = 0; t < 6; t++) {
+                    const int slot = (S + 1 + t) % 6;          // t = 0: oldest row (i - 5)
+                    const int k = kv + 2 * t;
+                    TapRow& cur = (t & 1) ? rowB : rowA;
+                    TapRow& nxt = (t & 1) ? rowA : rowB;
+                    radial_row_wait(cur);
+                    if (t < 5) radial_row_issue(nxt, p.fu, FLIPU ? k + 2 : 11 - (k + 2));
+#pragma unroll
+                    for (int sx = 0; sx < 6; sx++) {
+                        const v2f tq = up2d_pair<FLIPU>(cur, sx);
+                        // column groups 0 / 1 read samples sx / sx + 1 of the row
+                        u0 = (sx & 1) ? fma_x_tap<1, FLIPU>(st.xw[slot][sx / 2], tq, u0) : fma_x_tap<0, FLIPU>(st.xw[slot][sx / 2], tq, u0);
+                        u1 = ((sx + 1) & 1) ? fma_x_tap<1, FLIPU>(st.xw[slot][(sx + 1) / 2], tq, u1) : fma_x_tap<0, FLIPU>(st.xw[slot][(sx + 1) / 2], tq, u1);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 6 && !UP2D; t++) {
                 const int slot = (S + 1 + t) % 6;              // t = 0: oldest row (i - 5)
                 const int k = kv + U * t;
                 // tap k lives in the reversed pair k/2: odd k = low half, even k = high half
@@ -324,7 +373,7 @@ struct Stream {
             }
             const v2f r0 = {a[0], a[1]}, r1 = {a[2], a[3]};
             const int kp = (VPH + S * U + j) % D;              // down phase of this row (a trip starts at phase VPH)
-            if (RADIAL) {
+            if (RDOWN) {
                 // ---- full 2-D down filter (config R): the activated row is exchanged through LDS once (each lane reads
                 // the 16 samples under its two output columns) and scattered into the six output rows it belongs to, one
                 // even/odd polyphase pass per output row with that row's 12 taps.  The 144 taps do not fit the scalar
@@ -439,7 +488,8 @@ struct Stream {
 
     static __device__ __forceinline__ void run(const StreamParams& p) {
         static_assert((D == 2 || D == 4) && (6 * U) % D == 0, "streaming kernel: down is 2 or 4");
-        static_assert(RADIAL == 0 || (D == 2 && SIGNS != 2), "radial variant: forward passes (plain or sign-writing), down 2");
+        static_assert(RADIAL < 1 || RADIAL > 2 || (D == 2 && SIGNS != 2), "radial down filter: forward passes (plain or sign-writing), down 2");
+        static_assert(RADIAL < 3 || (U == 2 && SIGNS == 2), "2-D up filter: the adjoint pass, up 2");
         __shared__ __attribute__((aligned(16))) float lds[Cfg::SIN + Cfg::SOUT];
         lds_f* sIn = (lds_f*)lds;
         lds_f* sOut = (lds_f*)lds + Cfg::SIN;                               // row exchanged for the horizontal down pass
@@ -474,10 +524,11 @@ struct Stream {
         const float gU = (float)U;
 #pragma unroll
         for (int m = 0; m < Cfg::FU / 2; m++) {
+            if (RADIAL >= 3) { st.tuP[m] = splat(0.f); continue; }          // 2-D up filter: rows stream from the scalar cache
             const float f1 = p.fu[p.flip ? 2 * m + 1 : Cfg::FU - 2 - 2 * m], f0 = p.fu[p.flip ? 2 * m : Cfg::FU - 1 - 2 * m];
             st.tuP[m] = (v2f){to_sgpr(f1 * gU), to_sgpr(f0 * gU)};
         }
-        if (RADIAL) {
+        if (RADIAL == 1 || RADIAL == 2) {
 #pragma unroll
             for (int m = 0; m < Cfg::FD / 2; m++) st.tdP[m] = splat(0.f);      // unused: the 12x12 taps stream from the scalar cache
         } else {
@@ -519,6 +570,8 @@ struct Stream {
 #pragma unroll
         for (int s = 0; s < 6; s++) {
             st.w[s][0] = splat(0.f); st.w[s][1] = splat(0.f);
+#pragma unroll
+            for (int q = 0; q < 4; q++) st.xw[s][q] = splat(0.f);
             st.acc[s][0] = splat(0.f); st.acc[s][1] = splat(0.f);
             prefetch(st, s, p, plane, splane, iFirst + s);
         }
@@ -583,7 +636,11 @@ flrelu_pointwise_kernel(PointParams p) {
 
 // ---------------------------------------------------------------------------
 static bool stream_supported(int up, int down, int fuW, int fuH, int fdW, int fdH) {
-    if (fuH != 0) return false;                               // separable up filter
+    if (fuH == 12) {
+        // adjoint of the radial (config R) layers: 12x12 up filter, up 2, separable down 2 (12 taps) or 4 (24 taps)
+        return up == 2 && fuW == 12 && fdH == 0 && ((down == 2 && fdW == 12) || (down == 4 && fdW == 24));
+    }
+    if (fuH != 0) return false;                               // otherwise a separable up filter
     if (fdH != 0 && fdH != 12) return false;                  // separable, or full 12x12 (radial) down filter
     if (down == 2 && fdW == 12) return (up == 2 && fuW == 12) || (up == 4 && fuW == 24);
     // adjoint of the up-4 layers: up 2 (12 taps), down 4 (24 taps), separable
@@ -592,7 +649,8 @@ static bool stream_supported(int up, int down, int fuW, int fuH, int fdW, int fd
 
 // the streaming kernel evaluates lrelu as max(v, slope * v), valid for 0 <= slope <= 1 (every StyleGAN3 layer)
 static bool stream_params_ok(const sg3_filtered_lrelu_params& q) {
-    if (q.fdH != 0 && ((uintptr_t)q.fd & 15) != 0) return false;  // radial taps are fetched as 16-byte scalar quads
+    if (q.fdH != 0 && ((uintptr_t)q.fd & 15) != 0) return false;  // 2-D taps are fetched as 16-byte scalar quads
+    if (q.fuH != 0 && (((uintptr_t)q.fu & 15) != 0 || !q.readSigns)) return false;       // 2-D up filter: adjoint passes only
     const bool signs = q.writeSigns || q.readSigns;
     if (signs && (!q.s || q.sH <= 0 || q.sWbytes <= 0)) return false;
     if (q.readSigns && q.fdH != 0) return false;                                          // adjoint passes: separable down filter
@@ -640,13 +698,18 @@ static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
 #define SG3_STREAM_LAUNCH(U, D, V, R, S) hipLaunchKernelGGL((flrelu_stream_kernel<T, U, D, V, R, S>), g, b, 0, st, p)
 #define SG3_STREAM_LAUNCH_V(U, R, S) do { if (vph == 0) SG3_STREAM_LAUNCH(U, 2, 0, R, S); else SG3_STREAM_LAUNCH(U, 2, 1, R, S); } while (0)
     if (q.readSigns) {
-        if (q.down == 2) SG3_STREAM_LAUNCH_V(2, 0, 2);
-        else switch (vph) {
-            case 0: SG3_STREAM_LAUNCH(2, 4, 0, 0, 2); break;
-            case 1: SG3_STREAM_LAUNCH(2, 4, 1, 0, 2); break;
-            case 2: SG3_STREAM_LAUNCH(2, 4, 2, 0, 2); break;
-            default: SG3_STREAM_LAUNCH(2, 4, 3, 0, 2); break;
-        }
+#define SG3_ADJOINT_LAUNCH(R) do { \
+        if (q.down == 2) SG3_STREAM_LAUNCH_V(2, R, 2); \
+        else switch (vph) { \
+            case 0: SG3_STREAM_LAUNCH(2, 4, 0, R, 2); break; \
+            case 1: SG3_STREAM_LAUNCH(2, 4, 1, R, 2); break; \
+            case 2: SG3_STREAM_LAUNCH(2, 4, 2, R, 2); break; \
+            default: SG3_STREAM_LAUNCH(2, 4, 3, R, 2); break; \
+        } } while (0)
+        if (q.fuH == 0) SG3_ADJOINT_LAUNCH(0);
+        else if (q.flip) SG3_ADJOINT_LAUNCH(4);
+        else SG3_ADJOINT_LAUNCH(3);
+#undef SG3_ADJOINT_LAUNCH
     } else if (q.writeSigns) {
         const int variant = q.fdH == 0 ? 0 : (q.flip ? 2 : 1);
         if (q.up == 2) {

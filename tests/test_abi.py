@@ -82,7 +82,9 @@ def test_shape_errors_and_kernel_table():
     assert lib.sg3_filtered_lrelu_has_kernel(4, 2, 24, 0, 12, 0) == 1      # config-T up4/down2
     assert lib.sg3_filtered_lrelu_has_kernel(1, 1, 1, 1, 1, 1) == 1        # ToRGB
     assert lib.sg3_filtered_lrelu_has_kernel(2, 2, 12, 0, 12, 12) == 1     # config-R radial 12x12 down filter
-    assert lib.sg3_filtered_lrelu_has_kernel(2, 2, 12, 12, 12, 0) == 0     # 2-D up filter -> generic composition
+    assert lib.sg3_filtered_lrelu_has_kernel(2, 2, 12, 12, 12, 0) == 1     # adjoint of the radial up-2 layers (12x12 up filter)
+    assert lib.sg3_filtered_lrelu_has_kernel(2, 4, 12, 12, 24, 0) == 1     # adjoint of the radial up-4 layers
+    assert lib.sg3_filtered_lrelu_has_kernel(4, 2, 24, 24, 12, 0) == 0     # any other 2-D up filter -> generic composition
     assert lib.sg3_filtered_lrelu_has_kernel(2, 4, 12, 0, 24, 0) == 1      # adjoint of the up-4 layers (sign-read calls)
     assert lib.sg3_modconv_packed_floats(512, 512, 3, _sg3abi.SG3_CONV_FP32) == 512 * 64 * 9 * 8
     assert lib.sg3_modconv_packed_floats(81, 128, 3, _sg3abi.SG3_CONV_FP32) == 81 * 16 * 9 * 8

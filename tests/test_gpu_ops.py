@@ -189,31 +189,39 @@ def test_filtered_lrelu_fused_sign_kernels(shape, up, taps, pad, clamp):
     assert float(diff) <= 1e-4, float(diff)
 
 
-def test_filtered_lrelu_radial_sign_writing_forward():
-    """Config-R training forward: the fused radial kernel also writes the sign tensor (the adjoint of these layers still
-    runs the generic composition); output and gradient against autograd through the reference formulation on the CPU."""
+@pytest.mark.parametrize('shape,up,taps,pad,clamp', [
+    ((1, 2, 84, 150), 2, 12, [11, 10, 11, 10], 1.5),            # config-R up-2 layer; adjoint: 12x12 up filter, down 2
+    ((2, 2, 84, 84), 4, 24, [-2, -5, -2, -5], 256),             # config-R up-4 layer; adjoint: 12x12 up filter, down 4
+    ((1, 1, 150, 276), 4, 24, [-2, -5, -2, -5], None),          # several strips / row chunks
+])
+def test_filtered_lrelu_radial_training_kernels(shape, up, taps, pad, clamp):
+    """Config-R training: the fused radial kernel writes the sign tensor and its adjoint (2-D 12x12 UP filter streamed from
+    the scalar cache, sign read, separable down 2 / 4) runs fused too; output and gradients against autograd through the
+    reference formulation on the CPU."""
     from oracle import oracle as O
     from torch_utils.ops import filtered_lrelu as fl
+    from torch_utils import _sg3abi
     fl._init()
-    fu = O.design_lowpass_filter(12, 4.0, 8.0, 64.0)
+    fu = O.design_lowpass_filter(taps, 4.0, 8.0, 64.0 * up / 2)
     fd = O.design_lowpass_filter(12, 5.0, 9.0, 64.0, radial=True)
-    xn, bn = rand(3, 1, 2, 84, 150), rand(4, 2)
-    kw = dict(up=2, down=2, padding=[11, 10, 11, 10], gain=float(np.sqrt(2)), slope=0.2, clamp=1.5, flip_filter=False)
-    y0, so, rc = fl._plugin.filtered_lrelu(T(xn), T(fu), T(fd), T(bn), torch.empty(0), 2, 2, 11, 10, 11, 10, 0, 0, kw['gain'], 0.2, 1.5, False, True)
-    assert rc == 0 and so.numel() > 0
-    xr = torch.from_numpy(xn).requires_grad_(True); br = torch.from_numpy(bn).requires_grad_(True)
-    yr = fl.filtered_lrelu(xr, torch.from_numpy(fu), torch.from_numpy(fd), br, impl='ref', **kw)
-    gy = rand(5, *yr.shape)
-    (yr * torch.from_numpy(gy)).sum().backward()
-    x = T(xn).requires_grad_(True); b = T(bn).requires_grad_(True)
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
+    fd = (fd + 0.01 * np.random.RandomState(8).rand(12, 12).astype(np.float32)).astype(np.float32)        # break the symmetry: exposes flips
+    xn, bn = rand(3, *shape), rand(4, shape[1])
+    for flip in (False, True):
+        kw = dict(up=up, down=2, padding=pad, gain=float(np.sqrt(2)), slope=0.2, clamp=clamp, flip_filter=flip)
+        cl = float('inf') if clamp is None else clamp
+        y0, so, rc = fl._plugin.filtered_lrelu(T(xn), T(fu), T(fd), T(bn), torch.empty(0), up, 2, *pad, 0, 0, kw['gain'], 0.2, cl, flip, True)
+        assert rc == 0 and so.numel() > 0
+        assert _sg3abi.load().sg3_filtered_lrelu_has_kernel(2, up, 12, 12, taps, 0) == 1      # the adjoint's shape
+        xr = torch.from_numpy(xn).requires_grad_(True); br = torch.from_numpy(bn).requires_grad_(True)
+        yr = fl.filtered_lrelu(xr, torch.from_numpy(fu), torch.from_numpy(fd), br, impl='ref', **kw)
+        gy = rand(5, *yr.shape)
+        (yr * torch.from_numpy(gy)).sum().backward()
+        x = T(xn).requires_grad_(True); b = T(bn).requires_grad_(True)
         y = fl.filtered_lrelu(x, T(fu), T(fd), b, **kw)
         (y * T(gy)).sum().backward()
-    assert maxabs(y0.cpu().numpy(), yr.detach().numpy()) <= 2e-5 and maxabs(y.detach().cpu().numpy(), yr.detach().numpy()) <= 2e-5
-    assert maxabs(x.grad.cpu().numpy(), xr.grad.numpy()) <= 5e-5
-    assert maxabs(b.grad.cpu().numpy(), br.grad.numpy()) <= 2e-3 * max(1.0, float(br.grad.abs().max()))
+        assert maxabs(y0.cpu().numpy(), yr.detach().numpy()) <= 2e-5 and maxabs(y.detach().cpu().numpy(), yr.detach().numpy()) <= 2e-5
+        assert maxabs(x.grad.cpu().numpy(), xr.grad.numpy()) <= 5e-5, flip
+        assert maxabs(b.grad.cpu().numpy(), br.grad.numpy()) <= 2e-3 * max(1.0, float(br.grad.abs().max()))
 
 
 def test_filtered_lrelu_act_signs_roundtrip():
