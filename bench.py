@@ -149,11 +149,11 @@ def bench_inversion(G, device, rank, world, frames_per_gpu=16, restyle_steps=5, 
                          'ranks, all-gather of [F,16,512] latents; synthetic weights')
 
 
-def bench_pti_step(device, steps=4):
+def bench_pti_step(device, cfg='T1024', steps=4):
     """One pivotal-tuning step (reference run_pti_images.py:126-139): fp32 synthesis forward with sign write, MSE, backward
-    through the fused adjoint / gradient kernels, Adam over the synthesis weights; batch 1, FFHQ-1024 config T."""
+    through the fused adjoint / gradient kernels, Adam over the synthesis weights; batch 1, FFHQ-1024."""
     from synth_weights import synth_ws
-    G = build_generator('T1024', device)
+    G = build_generator(cfg, device)
     G.requires_grad_(True)
     opt = torch.optim.Adam(list(G.synthesis.parameters())[3:], lr=3e-4)
     w = torch.from_numpy(synth_ws(1, G.num_ws, G.w_dim, seed=3)).to(device)
@@ -196,7 +196,8 @@ def bench_extras(G, ws, device, steps=5):
 
     G.synthesis.input.transform = torch.eye(3, device=device)     # the inversion measurement leaves per-frame transforms behind
     out = {'T1024_mixed_fp16': run(G, ws)}
-    out['T1024_pti_step'] = bench_pti_step(device)
+    out['T1024_pti_step'] = bench_pti_step(device, 'T1024')
+    out['R1024_pti_step'] = bench_pti_step(device, 'R1024')
     for cfg, batch in (('R1024', 4), ('R512', 8)):
         gen = build_generator(cfg, device)
         w = torch.from_numpy(synth_ws(batch, gen.num_ws, gen.w_dim, seed=1)).to(device)
