@@ -7,18 +7,20 @@
 //
 // so all samples share one weight matrix:  M = O (out channels), N = pixels, K = I*k*k.
 //
-//   * arithmetic: v_mfma_f32_32x32x2_f32 -- exact fp32 products and fp32 accumulation (bitwise an fmaf chain), which
-//     is what the 1e-4 end-to-end parity target needs; 4 k-steps are fetched per ds_read_b128 for each operand;
-//   * A (weights) is pre-packed by the prep kernel as [O][I/KC][taps][KC] so a workgroup's A tile is a straight
-//     16-byte-per-lane copy into LDS rows of taps*KC+4 floats (the +4 makes the 32-row ds_read_b128 conflict free);
-//   * B is never materialised: the input patch (tile + halo) of KC channels is staged once in LDS, scaled by sIn on
-//     the way in, channel-interleaved by 4 so that the im2col view for tap (ky,kx) is one conflict-free
-//     ds_read_b128 per lane at a shifted offset;
-//   * the next K-chunk is fetched global->registers while the current one is in the MFMA loop (issue-early /
-//     write-late), one barrier pair per chunk;
-//   * tile shapes are picked per layer so odd StyleGAN3 channel counts (323, 203, 81, 51, 32, 3) keep the M
-//     dimension busy: BM in {128, 96, 64, 32} with more pixel rows per workgroup as BM shrinks;
-//   * block ids are renumbered so the M-tiles that share an input patch, and neighbouring patches, sit on one XCD.
+// Kernels in this file (the host picks one per call, see sg3_modulated_conv2d):
+//   * modconv_f16x3_kernel   3x3, split precision (fp16 hi/lo operands, three fp16 MFMAs per product, fp32-equivalent) or
+//                            plain fp16 (the reference's mixed-precision layers): the default when |x| is bounded;
+//   * modconv1_f16x3_kernel  1x1 (config R), same arithmetic, a plain GEMM over flat 256-pixel tiles;
+//   * modconv_mfma_kernel    3x3 / 1x1, v_mfma_f32_32x32x2_f32: exact fp32 products (bitwise an fmaf chain), for inputs
+//                            without a bound;
+//   * modconv_1x1_small_kernel  ToRGB (O <= 4): HBM-bound, no matrix cores;
+//   * modconv_prep_{w,s}_kernel  weight normalisation + packing, style normalisation, demodulation coefficients.
+// Common scheme: A (weights) pre-packed per K chunk so a workgroup's A tile is a straight 16-byte-per-lane copy into
+// padded LDS rows; B never materialised: the input patch (tile + halo) of one K chunk is staged once in LDS, scaled by
+// sIn on the way in, channel-interleaved so that the im2col view of tap (ky,kx) is one conflict-free ds_read_b128 per
+// lane at a shifted offset; the next chunk is fetched global->registers while the current one is in the MFMA loop;
+// tile shapes per layer so that odd channel counts (323, 203, 81, 51, 32, 3) keep the M dimension busy; block ids
+// renumbered so that the M tiles sharing an input patch, and neighbouring patches, sit on one XCD.
 //
 // demodulation (dcoef) is applied in the epilogue; bias/activation belong to the following filtered_lrelu.
 #include "sg3_common.h"

@@ -2,10 +2,10 @@
 
 `BackboneEncoder` (:10-50): conv3x3(input_nc -> 64) + BN + PReLU at 256^2, the IR / IR-SE stages down to [N,512,16,16],
 then `n_styles` GradualStyleBlock heads, stacked to [N, n_styles, 512].  Module names and therefore state_dict keys are
-the reference's.  In eval mode on a GPU the forward runs on libsg3hip's matrix-core convolution with BatchNorm / PReLU
-/ leaky-ReLU fused, and the first convolution of all heads (same input) is executed as ONE convolution with
-n_styles*512 output channels.  `ResNetBackboneEncoder` (:53-97) needs torchvision's pretrained ResNet34, which is
-neither installed nor downloadable here; constructing it raises with that explanation.
+the reference's.  In eval mode on a GPU the backbone runs on libsg3hip's matrix-core convolution with BatchNorm / PReLU
+fused, and the style heads (tiny maps, weight-bandwidth bound) as batched GEMMs over all heads on unfolded patches.
+`ResNetBackboneEncoder` (:53-97) needs torchvision's pretrained ResNet34, which is neither installed nor downloadable
+here; constructing it raises with that explanation.
 """
 import torch
 from torch import nn
@@ -56,7 +56,7 @@ class BackboneEncoder(Module):
         return super()._apply(fn, *args, **kwargs)
 
     def _pack(self):
-        from torch_utils.ops.plain_conv import ACT_LRELU, ACT_PRELU, PackedConv, bn_affine
+        from torch_utils.ops.plain_conv import ACT_PRELU, PackedConv, bn_affine
         conv, bn, prelu = self.input_layer[0], self.input_layer[1], self.input_layer[2]
         a, b = bn_affine(bn)
         pk = dict(stem=PackedConv(conv.weight, out_scale=a, bias=b, act=ACT_PRELU, slope=prelu.weight, stride=1, padding=1))

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import build_oracle_generator, build_product_generator, golden, maxabs
+from helpers import build_product_generator, golden, maxabs
 from synth_weights import make_user_transform, synth_ws
 
 pytestmark = pytest.mark.gpu
