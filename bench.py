@@ -202,6 +202,20 @@ def bench_extras(G, ws, device, steps=5):
         gen = build_generator(cfg, device)
         w = torch.from_numpy(synth_ws(batch, gen.num_ws, gen.w_dim, seed=1)).to(device)
         out[cfg + '_fp32'] = run(gen, w, force_fp32=True)
+        if cfg == 'R512':
+            # BASELINE configs[4]: StyleCLIP global-direction sweep, 5 betas x 11 alphas of one latent, rendered as
+            # StyleSpace batches of 32 (the reference renders the 55 edits one by one)
+            from editing.styleclip_global_directions.edit import render_sweep
+            with torch.no_grad():
+                base = gen.synthesis.W2S(w[:1])
+                sweep = {c: v.repeat(55, 1) * (1 + 0.01 * torch.arange(55, device=device).view(-1, 1)) for c, v in base.items()}
+                render_sweep(gen, sweep, max_batch=32, force_fp32=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                render_sweep(gen, sweep, max_batch=32, force_fp32=True)
+                torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out['R512_styleclip_sweep'] = {'edits_per_s': 55 / dt, 'ms_per_sweep': dt * 1e3, 'edits': 55, 'max_batch': 32}
         del gen
         torch.cuda.empty_cache()
     return out
