@@ -15,6 +15,17 @@ from models.setgan.encoder.encoders.helpers import bottleneck_IR, bottleneck_IR_
 from models.setgan.encoder.encoders.map2style import GradualStyleBlock
 
 
+def _patches_3x3_s2(h):
+    """im2col of a 3x3, stride-2, padding-1 convolution: [B,C,H,W] -> [B, C*9, (H/2)*(W/2)] in F.unfold's ordering
+    (channel-major, then ky, kx).  Nine strided slices and one stack: F.unfold launches one kernel per batch element, and
+    the heads run with B = heads * N."""
+    b, c, hh, ww = h.shape
+    oh, ow = (hh + 1) // 2, (ww + 1) // 2
+    hp = torch.nn.functional.pad(h, (1, 1, 1, 1))
+    taps = [hp[:, :, ky:ky + 2 * oh - 1:2, kx:kx + 2 * ow - 1:2] for ky in range(3) for kx in range(3)]
+    return torch.stack(taps, dim=2).reshape(b, c * 9, oh * ow)
+
+
 class BackboneEncoder(Module):
     def __init__(self, num_layers, mode='ir', n_styles=18, opts=None):
         super().__init__()
@@ -99,13 +110,13 @@ class BackboneEncoder(Module):
             x = unit.forward_hip(x)
         n, heads, c = int(x.shape[0]), len(self.styles), self.styles[0].out_c
         side = (int(x.shape[2]) + 1) // 2
-        cols = torch.nn.functional.unfold(x, kernel_size=3, padding=1, stride=2)                      # [N, C*9, side^2]
+        cols = _patches_3x3_s2(x)                                                                     # [N, C*9, side^2]
         cols = cols.permute(0, 2, 1).reshape(n * side * side, -1)
         h = torch.nn.functional.leaky_relu(torch.addmm(pk['head0_b'], cols, pk['head0_w']), pk['slope'])   # [N*side^2, heads*C]
         h = h.view(n, side, side, heads, c).permute(3, 0, 4, 1, 2).reshape(heads * n, c, side, side)
         for w, b in zip(pk['tail_w'], pk['tail_b']):
             side = (int(h.shape[2]) + 1) // 2
-            cols = torch.nn.functional.unfold(h, kernel_size=3, padding=1, stride=2)               # [heads*N, C*9, side^2]
+            cols = _patches_3x3_s2(h)                                                              # [heads*N, C*9, side^2]
             cols = cols.view(heads, n, c * 9, side * side).permute(0, 1, 3, 2).reshape(heads, n * side * side, c * 9)
             h = torch.nn.functional.leaky_relu(torch.baddbmm(b, cols, w), pk['slope'])           # [heads, N*side^2, C]
             h = h.view(heads, n, side, side, c).permute(0, 1, 4, 2, 3).reshape(heads * n, c, side, side)
