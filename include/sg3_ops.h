@@ -101,9 +101,15 @@ typedef struct sg3_filtered_lrelu_params {
     int32_t        flip;       /* 1 = correlation (flip_filter=True) */
     int32_t        writeSigns;
     int32_t        readSigns;
+    float*         ySumPartial; /* optional [N*C, sg3_filtered_lrelu_sum_slots(...)]: per-workgroup sums of the outputs of each
+                                 * plane (fused kernels only).  The caller adds them up: the bias gradient db = dx.sum([0,2,3])
+                                 * of the adjoint pass (torch_utils/ops/filtered_lrelu.py:266-267) without re-reading dx */
 } sg3_filtered_lrelu_params;
 
 SG3_API int sg3_filtered_lrelu(const sg3_filtered_lrelu_params* p, void* stream);
+
+/* number of partial sums per (n,c) plane that sg3_filtered_lrelu writes to ySumPartial for this output shape */
+SG3_API int sg3_filtered_lrelu_sum_slots(int N, int C, int yH, int yW, int down);
 
 /* 1 when sg3_filtered_lrelu has a fused kernel for this tuple (host-only
  * query; mirrors the reference's choose_filtered_lrelu_kernel test call,

@@ -58,6 +58,7 @@ struct StreamParams {
     int totalBlocks;
     float gain, slope, clamp;
     int flip;
+    float* ysum;                   // optional [N*C][nChunks*nStrips]: sum of this block's outputs (bias gradient of the adjoint pass)
     unsigned char* s;              // sign tensor [N*C][sH][sWb] (2 bits per upsampled sample, 4 per byte), or null
     int sH, sWb, sx, sy;           // rows, bytes per row, offset of the upsampled buffer inside the sign tensor
 };
@@ -203,6 +204,7 @@ struct WaveState {
                                   // as they stand, and the source of the V-up tap splats (odd tap = low half)
     v2f tdP[Cfg::FD / 2];         // down taps (td[2m], td[2m+1]): V-down splats and H-down even/odd pairs
     unsigned sg[6][U];            // sign-read mode: prefetched sign bytes (this lane's byte | next byte << 8) per upsampled row
+    float osum;                   // running sum of the outputs this lane stored (only kept when p.ysum is given)
     int soff;                     // sign modes: byte offset, inside a sign row, of the byte holding this lane's first column
     int sq;                       // sign modes: position (0..3) of that column inside its byte (wave-uniform)
 };
@@ -415,6 +417,7 @@ struct Stream {
                     if (oy >= oy0 && oy < oy1) {                   // wave-uniform
                         const v2f y0 = st.acc[headR][0], y1 = st.acc[headR][1];
                         const float f0 = (y0.x + y0.y) * gainOut, f1 = (y1.x + y1.y) * gainOut;
+                        st.osum += (2 * lane < oxN ? f0 : 0.f) + (2 * lane + 1 < oxN ? f1 : 0.f);
                         T* orow = oplane + (long long)oy * p.ysH + ox0;
                         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)orow, (short)0, oxN * (int)sizeof(T), 0x00020000);
                         if (pairStore) {
@@ -464,6 +467,7 @@ struct Stream {
 #pragma unroll
                         for (int q = 1; q < Cfg::FD / 2; q++) { y0 = fma2(pr[q], st.tdP[q], y0); y1 = fma2(pr[q + 1], st.tdP[q], y1); }
                         const float f0 = (y0.x + y0.y) * gainOut, f1 = (y1.x + y1.y) * gainOut;
+                        st.osum += (2 * lane < oxN ? f0 : 0.f) + (2 * lane + 1 < oxN ? f1 : 0.f);
                         if (pairStore) {
                             bufio<T>::st2(rs, 2 * lane * (int)sizeof(T), f0, f1);
                         } else {
@@ -478,7 +482,9 @@ struct Stream {
                         v2f y0 = pr[0] * st.tdP[0];
 #pragma unroll
                         for (int q = 1; q < Cfg::FD / 2; q++) y0 = fma2(pr[q], st.tdP[q], y0);
-                        bufio<T>::st1(rs, lane * (int)sizeof(T), (y0.x + y0.y) * gainOut);
+                        const float f0 = (y0.x + y0.y) * gainOut;
+                        st.osum += lane < oxN ? f0 : 0.f;
+                        bufio<T>::st1(rs, lane * (int)sizeof(T), f0);
                     }
                     wave_lds_sync();
                 }
@@ -551,6 +557,7 @@ struct Stream {
             st.bcol[q] = ((unsigned)ix < (unsigned)p.xW) ? bias : 0.f;
         }
 
+        st.osum = 0.f;
         if (SIGNS) {
             const int c0 = uxs + p.sx;                           // sign-tensor column of lane 0's first upsampled column
             st.sq = to_sgpr_i(((c0 % 4) + 4) % 4);
@@ -592,6 +599,12 @@ struct Stream {
 #pragma unroll
                     for (int h = 0; h < 2; h++) { const v2f t = st.acc[r][h]; st.acc[r][h] = st.acc[r + 3][h]; st.acc[r + 3][h] = t; }
             }
+        }
+        if (p.ysum) {
+            float v = st.osum;
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+            if (lane == 0) p.ysum[(long long)plane_id * (p.nChunks * p.nStrips) + chunk * p.nStrips + strip] = v;
         }
     }
 };
@@ -663,6 +676,23 @@ static bool pointwise_supported(int up, int down, int fuW, int fuH, int fdW, int
     return up == 1 && down == 1 && fuW == 1 && fdW == 1 && fuH <= 1 && fdH <= 1;
 }
 
+// Work decomposition of the streaming kernel: strips of equal width, as wide as a wave's 256 upsampled columns can complete
+// (120 for down 2, 58 for down 4); row chunks: enough waves to fill 256 CUs x 16 waves a few times over, but chunks tall
+// enough that the 11-row warm-up stays small.
+static void stream_grid(int N, int C, int yH, int yW, int down, int& nStrips, int& TW, int& nChunks, int& CH) {
+    const int maxTW = (256 - 6 * down) / down;
+    nStrips = ceil_div(yW, maxTW);
+    TW = ceil_div(yW, nStrips);
+    const long long planes = (long long)N * C;
+    const long long wantWaves = 256LL * 16 * 4;
+    int n = (int)ceil_div64(wantWaves, planes * nStrips);
+    const int maxChunks = max(1, yH / 48);
+    if (n > maxChunks) n = maxChunks;
+    if (n < 1) n = 1;
+    CH = ceil_div(yH, n);
+    nChunks = ceil_div(yH, CH);
+}
+
 template <typename T>
 static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
     StreamParams p;
@@ -675,20 +705,9 @@ static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
     p.gain = q.gain; p.slope = q.slope; p.clamp = q.clamp; p.flip = q.flip;
 
     p.s = q.s; p.sH = q.sH; p.sWb = q.sWbytes; p.sx = q.sx; p.sy = q.sy;
-    // strips: equal widths, as wide as a wave's 256 upsampled columns can complete (120 for down 2, 58 for down 4)
-    const int maxTW = (256 - 6 * q.down) / q.down;
-    p.nStrips = ceil_div(q.yW, maxTW);
-    p.TW = ceil_div(q.yW, p.nStrips);
-    // row chunks: enough waves to fill 256 CUs x 16 waves a few times over, but chunks tall enough that the
-    // 11-row warm-up stays small
+    p.ysum = q.ySumPartial;
+    stream_grid(q.N, q.C, q.yH, q.yW, q.down, p.nStrips, p.TW, p.nChunks, p.CH);
     const long long planes = (long long)q.N * q.C;
-    const long long wantWaves = 256LL * 16 * 4;
-    int nChunks = (int)ceil_div64(wantWaves, planes * p.nStrips);
-    const int maxChunks = max(1, q.yH / 48);
-    if (nChunks > maxChunks) nChunks = maxChunks;
-    if (nChunks < 1) nChunks = 1;
-    p.CH = ceil_div(q.yH, nChunks);
-    p.nChunks = ceil_div(q.yH, p.CH);
     const long long total = planes * p.nStrips * p.nChunks;
     if (total > 0x7fffffffLL) { set_error("filtered_lrelu: grid too large"); return SG3_BAD_ARG; }
     p.totalBlocks = (int)total;
@@ -753,6 +772,13 @@ extern "C" {
 
 int sg3_filtered_lrelu_has_kernel(int up, int down, int fuW, int fuH, int fdW, int fdH) {
     return (sg3::stream_supported(up, down, fuW, fuH, fdW, fdH) || sg3::pointwise_supported(up, down, fuW, fuH, fdW, fdH)) ? 1 : 0;
+}
+
+int sg3_filtered_lrelu_sum_slots(int N, int C, int yH, int yW, int down) {
+    if (N <= 0 || C <= 0 || yH <= 0 || yW <= 0 || (down != 2 && down != 4)) return 0;
+    int nStrips, TW, nChunks, CH;
+    sg3::stream_grid(N, C, yH, yW, down, nStrips, TW, nChunks, CH);
+    return nStrips * nChunks;
 }
 
 int sg3_filtered_lrelu_shape(int xH, int xW, int up, int down, int fuW, int fuH, int fdW, int fdH,

@@ -28,8 +28,9 @@ class FilteredLreluPlugin:
     name = 'filtered_lrelu_plugin'
 
     @staticmethod
-    def filtered_lrelu(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, slope, clamp, flip_filters, writeSigns):
-        """-> (y, so, return_code).  return_code -1 (with empty tensors) = no fused kernel for this configuration."""
+    def filtered_lrelu(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, slope, clamp, flip_filters, writeSigns, return_sum=False):
+        """-> (y, so, return_code).  return_code -1 (with empty tensors) = no fused kernel for this configuration.
+        `return_sum` (extension): also return y.sum([0,2,3]) per channel, accumulated by the kernel (-> (y, so, rc, ysum))."""
         _require(x.is_cuda, 'x must reside on CUDA device')
         _require(fu.device == x.device and fd.device == x.device and b.device == x.device, 'all input tensors must reside on the same device')
         _require(fu.dtype == torch.float32 and fd.dtype == torch.float32, 'fu and fd must be float32')
@@ -47,7 +48,7 @@ class FilteredLreluPlugin:
         fuW, fuH = int(fu.shape[-1]), (int(fu.shape[0]) if fu.ndim == 2 else 0)
         fdW, fdH = int(fd.shape[-1]), (int(fd.shape[0]) if fd.ndim == 2 else 0)
         if not lib.sg3_filtered_lrelu_has_kernel(int(up), int(down), fuW, fuH, fdW, fdH):
-            return torch.empty(0), torch.empty(0), -1
+            return (torch.empty(0), torch.empty(0), -1, None) if return_sum else (torch.empty(0), torch.empty(0), -1)
 
         N, C, xH, xW = (int(v) for v in x.shape)
         yH, yW, sH, sWb, swl = (ctypes.c_int() for _ in range(5))
@@ -88,10 +89,18 @@ class FilteredLreluPlugin:
         p.sx, p.sy, p.swLimit = int(sx), int(sy), int(sw_limit)
         p.gain, p.slope, p.clamp = float(gain), float(slope), float(clamp)
         p.flip, p.writeSigns, p.readSigns = int(bool(flip_filters)), int(bool(writeSigns)), int(bool(readSigns))
+        partial = None
+        if return_sum:
+            slots = int(lib.sg3_filtered_lrelu_sum_slots(N, C, yH.value, yW.value, int(down)))
+            if slots > 0:
+                partial = torch.empty([N, C, slots], dtype=torch.float32, device=x.device)
+                p.ySumPartial = abi.ptr(partial)
         with torch.cuda.device(x.device):
             rc = lib.sg3_filtered_lrelu(ctypes.byref(p), abi.stream_ptr(x.device))
         if abi.check(rc, 'sg3_filtered_lrelu', allow_no_kernel=True) == abi.SG3_NO_KERNEL:
-            return torch.empty(0), torch.empty(0), -1
+            return (torch.empty(0), torch.empty(0), -1, None) if return_sum else (torch.empty(0), torch.empty(0), -1)
+        if return_sum:
+            return y, so, 0, (partial.sum(dim=(0, 2)).to(x.dtype) if partial is not None else None)
         return y, so, 0
 
     @staticmethod

@@ -27,7 +27,7 @@ class FilteredLreluParams(ctypes.Structure):
                 ('up', c_i32), ('down', c_i32), ('fuW', c_i32), ('fuH', c_i32), ('fdW', c_i32), ('fdH', c_i32),
                 ('px0', c_i32), ('py0', c_i32), ('sH', c_i32), ('sWbytes', c_i32), ('sx', c_i32), ('sy', c_i32),
                 ('swLimit', c_i32), ('gain', c_f32), ('slope', c_f32), ('clamp', c_f32),
-                ('flip', c_i32), ('writeSigns', c_i32), ('readSigns', c_i32)]
+                ('flip', c_i32), ('writeSigns', c_i32), ('readSigns', c_i32), ('ySumPartial', c_vp)]
 
 
 class FilteredLreluActParams(ctypes.Structure):
@@ -81,6 +81,7 @@ EXPORTS = [
     ('sg3_device_count', ctypes.c_int, []),
     ('sg3_filtered_lrelu', ctypes.c_int, [ctypes.POINTER(FilteredLreluParams), c_vp]),
     ('sg3_filtered_lrelu_has_kernel', ctypes.c_int, [ctypes.c_int] * 6),
+    ('sg3_filtered_lrelu_sum_slots', ctypes.c_int, [ctypes.c_int] * 5),
     ('sg3_filtered_lrelu_shape', ctypes.c_int, [ctypes.c_int] * 12 + [ctypes.POINTER(ctypes.c_int)] * 5),
     ('sg3_filtered_lrelu_act', ctypes.c_int, [ctypes.POINTER(FilteredLreluActParams), c_vp]),
     ('sg3_upfirdn2d', ctypes.c_int, [ctypes.POINTER(Upfirdn2dParams), c_vp]),

@@ -185,9 +185,20 @@ def _filtered_lrelu_cuda(up=1, down=1, padding=0, gain=np.sqrt(2), slope=0.2, cl
                 gg = gain * (up ** 2) / (down ** 2)
                 sxb = sx - (fu.shape[-1] - 1) + px0
                 syb = sy - (fu.shape[0] - 1) + py0
-                dx = _filtered_lrelu_cuda(up=down, down=up, padding=pp, gain=gg, slope=slope, clamp=None,
-                                          flip_filter=(not flip_filter)).apply(dy, fd, fu, None, si, sxb, syb)
-            if ctx.needs_input_grad[3]:
+                if not torch.is_grad_enabled() and dy.dtype in (torch.float16, torch.float32):
+                    # first-order gradients: the fused adjoint kernel also accumulates the per-channel sum of dx, so the bias
+                    # gradient needs no second pass over dx
+                    zb = torch.zeros([dy.shape[1]], dtype=dy.dtype, device=dy.device)
+                    dxf, _, rc, db_f = _plugin.filtered_lrelu(dy.contiguous(), fd, fu, zb, si, down, up, pp[0], pp[1], pp[2], pp[3], sxb, syb,
+                                                              gg, slope, float('inf'), not flip_filter, False, return_sum=ctx.needs_input_grad[3])
+                    if rc == 0:
+                        dx = dxf
+                        if ctx.needs_input_grad[3] and db_f is not None:
+                            db = db_f
+                if dx is None:
+                    dx = _filtered_lrelu_cuda(up=down, down=up, padding=pp, gain=gg, slope=slope, clamp=None,
+                                              flip_filter=(not flip_filter)).apply(dy, fd, fu, None, si, sxb, syb)
+            if ctx.needs_input_grad[3] and db is None:
                 db = dx.sum([0, 2, 3])
             return dx, None, None, db, None, None, None
 
