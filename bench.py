@@ -264,11 +264,17 @@ def main():
         # the timed job replays ONE captured hipGraph per step; per-kernel HIP-event timing for the roofline line is
         # taken from an eager pass after the timed region (events cannot be recorded inside a graph replay)
         from sg3_runtime import GraphedSynthesis
-        graphed = GraphedSynthesis(G, args.batch)
         eager_step = step
-
-        def step():  # noqa: F811
-            return graphed(ws)
+        try:
+            graphed = GraphedSynthesis(G, args.batch)
+        except RuntimeError as err:                     # capture refused (e.g. by a runtime/driver combination): measure eagerly
+            print(f'[bench] hipGraph capture failed on rank {rank}, timing eager launches instead: {err}', file=sys.stderr, flush=True)
+            graphed = None
+            args.eager = True
+            torch.cuda.synchronize()
+        if graphed is not None:
+            def step():  # noqa: F811
+                return graphed(ws)
 
     for _ in range(args.warmup):
         step()

@@ -33,7 +33,9 @@ class GraphedSynthesis:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        # thread-local capture: other threads of the process (e.g. the RCCL watchdog of torch.distributed, which polls
+        # events) may keep calling into the runtime while this thread captures
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.static_out = self._eager()
 
     def _eager(self):
