@@ -242,7 +242,7 @@ def main():
     device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)      # 'nccl' IS RCCL on ROCm
 
     from torch_utils import _sg3abi
     _sg3abi.load()

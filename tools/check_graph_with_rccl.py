@@ -10,7 +10,7 @@ from synth_weights import synth_ws  # noqa: E402
 from sg3_runtime import GraphedSynthesis  # noqa: E402
 os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
 torch.cuda.set_device(0)
-dist.init_process_group('nccl', rank=0, world_size=1)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
 t = torch.ones(4, device='cuda'); dist.all_reduce(t); dist.barrier()
 G = build_product_generator('T256', device='cuda:0')
 ws = torch.from_numpy(synth_ws(2, G.num_ws, G.w_dim, 1)).cuda()
@@ -18,7 +18,6 @@ g = GraphedSynthesis(G, 2)
 a = g(ws).clone()
 with torch.no_grad():
     b = G.synthesis(ws, noise_mode='const', force_fp32=True)
-gathered = torch.empty_like(a); dist.all_gather_into_tensor(gathered, a[:]) if False else None
 dist.barrier()
 print('graph replay under an RCCL process group: max diff vs eager', float((a - b).abs().max()))
 dist.destroy_process_group()
