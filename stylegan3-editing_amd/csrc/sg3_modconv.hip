@@ -203,15 +203,14 @@ modconv_mfma_kernel(ConvParams p) {
 // planes [channel-half][hi|lo][py][px][8 halfs], so a lane's im2col fragment for tap (ky,kx) is one ds_read_b128.
 // SPLIT = false is the plain fp16 form (SG3_CONV_F16): operands rounded to fp16 once, ONE MFMA per K step -- the
 // arithmetic of the reference's fp16 layers (fp16 cuDNN convolution with fp32 accumulation).
-// ROWSTREAM selects the MFMA loop order.  false: tap by tap, every tap reading its own A and B fragments (2 TM + 2 TN
-// ds_read_b128 per 3 TM TN MFMAs).  true (TM == 1): column offset kx outermost, the three A fragments of that column
-// held in registers while the patch rows stream through: one B fragment serves up to three output rows (ky = 0..2), so
-// a wave issues 18 + 6 (TN + 2) reads per 27 TN MFMAs -- 0.5 per MFMA at TN = 4 against 0.67 / 1.0 for the 2x2 / 1x2
-// tap-by-tap tiles.  LDS bandwidth, not the matrix cores, bounds the tap-by-tap form.
-template <typename T, int WM, int WN, int TM, int TN, bool SPLIT, bool ROWSTREAM>
-__global__ void __launch_bounds__(256, (TM * TN <= 4) ? 2 : 1)      // two workgroups per CU whenever the accumulators allow
+// MFMA loop order: every wave owns ONE 32-channel M block and TN output rows; the column offset kx is outermost, the
+// three A fragments of that column are held in registers while the patch rows stream through, and one B fragment
+// serves up to three output rows (ky = 0..2): 18 + 6 (TN + 2) ds_read_b128 per 27 TN MFMAs (0.5 per MFMA at TN = 4;
+// a tap-by-tap loop over 2x2 blocks needs 0.67).
+template <typename T, int WM, int WN, int TN, bool SPLIT>
+__global__ void __launch_bounds__(256, 2)              // two workgroups per CU
 modconv_f16x3_kernel(ConvParams p) {
-    static_assert(!ROWSTREAM || TM == 1, "row streaming keeps one M block per wave");
+    constexpr int TM = 1;
     constexpr int KS = 3, TAPS = 9, KC = 16;
     constexpr int NPART = SPLIT ? 2 : 1;               // B planes per channel half: hi | lo
     constexpr int BM = WM * TM * 32;
@@ -337,43 +336,13 @@ modconv_f16x3_kernel(ConvParams p) {
         }
     };
 
-    // fragment loads for one tap; two register sets so tap t+1 is in flight while tap t's MFMAs issue
-    struct Frags { v8h ah[TM], al[TM], bh[TN], bl[TN]; };
-    auto load_frags = [&](Frags& f, int tap) {
-        const int ky = tap / KS, kx = tap % KS;
-#pragma unroll
-        for (int a = 0; a < TM; a++) {
-            const _Float16* src = sA + ((wm * TM + a) * 32 + li) * AS + tap * 32 + lh * 8;
-            f.ah[a] = *reinterpret_cast<const v8h*>(src);
-            if (SPLIT) f.al[a] = *reinterpret_cast<const v8h*>(src + 16);
-        }
-#pragma unroll
-        for (int b = 0; b < TN; b++) {
-            const _Float16* src = sB + (lh * NPART) * BPLANE + ((wn * TN + b + ky) * PW + li + kx) * 8;
-            f.bh[b] = *reinterpret_cast<const v8h*>(src);
-            if (SPLIT) f.bl[b] = *reinterpret_cast<const v8h*>(src + BPLANE);
-        }
-    };
-    auto mfma_tap = [&](const Frags& f) {
-#pragma unroll
-        for (int a = 0; a < TM; a++)
-#pragma unroll
-            for (int b = 0; b < TN; b++) {
-                if (SPLIT) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[a], f.bh[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bl[b], acc[a][b], 0, 0, 0);
-                }
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bh[b], acc[a][b], 0, 0, 0);
-            }
-    };
-
     fetch(0);
     for (int ch = 0; ch < p.nch; ch++) {
         __syncthreads();
         stage(ch);
         __syncthreads();
         if (ch + 1 < p.nch) fetch(ch + 1);
-        if (ROWSTREAM) {
+        {
             struct BFrag { v8h h, l; };
             auto load_b = [&](BFrag& f, int pr, int kx) {
                 const _Float16* src = sB + (lh * NPART) * BPLANE + ((wn * TN + pr) * PW + li + kx) * 8;
@@ -415,22 +384,6 @@ modconv_f16x3_kernel(ConvParams p) {
                         mfma_row(b1, ah, al, pr + 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                }
-            }
-        } else {
-            Frags f0, f1;
-            load_frags(f0, 0);
-#pragma unroll
-            for (int tap = 0; tap < TAPS; tap += 2) {
-                if (tap + 1 < TAPS) load_frags(f1, tap + 1);
-                __builtin_amdgcn_sched_barrier(0);          // keep the next tap's ds_reads ahead of this tap's MFMAs
-                mfma_tap(f0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (tap + 1 < TAPS) {
-                    if (tap + 2 < TAPS) load_frags(f0, tap + 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mfma_tap(f1);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -840,9 +793,9 @@ static int dispatch_conv(const sg3_modconv_params& q, hipStream_t st) {
     }
 }
 
-template <typename T, int WM, int WN, int TM, int TN, bool SPLIT, bool ROWSTREAM>
+template <typename T, int WM, int WN, int TN, bool SPLIT>
 static int launch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
-    constexpr int BM = WM * TM * 32, ROWS = WN * TN;
+    constexpr int BM = WM * 32, ROWS = WN * TN;
     constexpr int PH = ROWS + 2, PW = 34;
     constexpr size_t ldsBytes = ((size_t)BM * (9 * 32 + 8) + (SPLIT ? 4 : 2) * (size_t)PH * PW * 8) * sizeof(_Float16);
     ConvParams p;
@@ -854,7 +807,7 @@ static int launch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     const long long total = (long long)p.xTiles * p.yTiles * p.mTiles * q.N;
     if (total > 0x7fffffffLL) { set_error("modulated_conv2d: grid too large"); return SG3_BAD_ARG; }
     p.totalBlocks = (int)total;
-    auto kern = modconv_f16x3_kernel<T, WM, WN, TM, TN, SPLIT, ROWSTREAM>;
+    auto kern = modconv_f16x3_kernel<T, WM, WN, TN, SPLIT>;
     if (ldsBytes > 64 * 1024)
         SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), ldsBytes, st, p);
@@ -870,8 +823,8 @@ static int dispatch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     // small tile wins when it saves at least ~10 % of the rows.
     const int O = q.O;
     const int t32 = ceil_div(O, 32) * 32, t64 = ceil_div(O, 64) * 64;
-    if (O <= 32 || t32 * 10 <= t64 * 9) return launch_conv_f16x3<T, 1, 4, 1, 4, SPLIT, true>(q, st);      //  32 x (16 rows x 32)
-    return launch_conv_f16x3<T, 2, 2, 1, 4, SPLIT, true>(q, st);                                            //  64 x (8 rows x 32)
+    if (O <= 32 || t32 * 10 <= t64 * 9) return launch_conv_f16x3<T, 1, 4, 4, SPLIT>(q, st);      //  32 x (16 rows x 32)
+    return launch_conv_f16x3<T, 2, 2, 4, SPLIT>(q, st);                                            //  64 x (8 rows x 32)
 }
 
 template <typename T, int WM, int WN, int TM, int TN, bool SPLIT>
