@@ -558,13 +558,21 @@ modconv1_f16x3_kernel(ConvParams p) {
         const _Float16* cur = smh + (ch & 1) * BUF;
         const bool more = ch + 1 < p.nch;
         if (more) fetch(ch + 1);
-        Frags f0, f1;
-        load_frags(f0, cur, 0);
-        load_frags(f1, cur, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step(f0);
-        mfma_step(f1);
-        __builtin_amdgcn_sched_barrier(0);
+        if (TM * TN <= 4) {
+            Frags f0, f1;
+            load_frags(f0, cur, 0);
+            load_frags(f1, cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(f0);
+            mfma_step(f1);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {                                            // eight accumulator blocks: one fragment set at a time
+            Frags f;
+            load_frags(f, cur, 0);
+            mfma_step(f);
+            load_frags(f, cur, 1);
+            mfma_step(f);
+        }
         if (more) stage(smh + ((ch + 1) & 1) * BUF, ch + 1);       // the other buffer: its readers passed the previous barrier
         __syncthreads();
     }
@@ -850,9 +858,12 @@ static int launch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
 
 template <typename T, bool SPLIT>
 static int dispatch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
-    // the 128-row tile has twice the MFMAs per LDS fragment read and half the L2 re-reads of the 64-row one
-    if (q.O <= 64) return launch_conv1_f16x3<T, 1, 8, 2, 1, SPLIT>(q, st);        //  64 x (8 rows x 32)
-    return launch_conv1_f16x3<T, 2, 4, 2, 2, SPLIT>(q, st);                       // 128 x (8 rows x 32)
+    // every staged input element is used once per output-channel tile, so the tile is as tall as the channel padding
+    // allows: 256 rows (1024 -> 1024 @ 148^2 x 4: 0.88 ms against 1.05 ms with 128 rows and 1.25 ms with 64)
+    if (q.O <= 64) return launch_conv1_f16x3<T, 1, 8, 2, 1, SPLIT>(q, st);        //  64 x 256 pixels
+    const int t128 = ceil_div(q.O, 128) * 128, t256 = ceil_div(q.O, 256) * 256;
+    if (t256 <= t128) return launch_conv1_f16x3<T, 2, 4, 4, 2, SPLIT>(q, st);     // 256 x 256 pixels
+    return launch_conv1_f16x3<T, 2, 4, 2, 2, SPLIT>(q, st);                       // 128 x 256 pixels
 }
 
 } // namespace sg3
