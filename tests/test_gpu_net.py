@@ -111,3 +111,22 @@ def test_mixed_precision_default_path():
     d = (a - b).abs()
     print('mixed vs fp32: max', float(d.max()), 'mean', float(d.mean()))
     assert float(d.max()) <= 5e-2 and float(d.mean()) <= 3e-3
+
+
+def test_graphed_synthesis_replay_equals_eager():
+    """hipGraph replay (sg3_runtime.GraphedSynthesis: what bench.py times) returns the eager result bit for bit, for the
+    W path, for new inputs copied into the static buffers, and for the StyleSpace path."""
+    from sg3_runtime import GraphedSynthesis
+    G = build_product_generator('T256', device=DEV)
+    ws = T(synth_ws(2, G.num_ws, G.w_dim, seed=1))
+    ws2 = T(synth_ws(2, G.num_ws, G.w_dim, seed=2))
+    g = GraphedSynthesis(G, 2)
+    with torch.no_grad():
+        e1 = G.synthesis(ws, noise_mode='const', force_fp32=True)
+        e2 = G.synthesis(ws2, noise_mode='const', force_fp32=True)
+        assert torch.equal(g(ws).clone(), e1)
+        assert torch.equal(g(ws2).clone(), e2)
+        assert maxabs(e1[:1].cpu().numpy(), golden('net_t256')['T256/img']) <= 1e-4
+        all_s = G.synthesis.W2S(ws)
+        gs = GraphedSynthesis(G, 2, all_s_template=all_s)
+        assert torch.equal(gs(all_s=all_s).clone(), G.synthesis(None, all_s=all_s, noise_mode='const', force_fp32=True))
