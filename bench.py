@@ -97,6 +97,13 @@ class KernelTimer:
     def total_ms(self, key):
         return sum(e0.elapsed_time(e1) for e0, e1 in self.records[key])
 
+    def median_step_ms(self, key, per_step):
+        """Median over steps of the summed duration of the `per_step` launches of one step (the first eager step after a
+        graph replay pays for fresh allocations inside its brackets; a mean would carry that)."""
+        d = [e0.elapsed_time(e1) for e0, e1 in self.records[key]]
+        steps = [sum(d[i:i + per_step]) for i in range(0, len(d) - per_step + 1, per_step)]
+        return float(np.median(steps)) if steps else 0.0
+
 
 def cpu_baseline(cfg):
     """CPU oracle (oracle/: C + OpenMP restatement of the reference's ref path) on ONE image of the same workload."""
@@ -325,8 +332,9 @@ def main():
 
     if rank == 0:
         total_bytes, _ = flrelu_algorithmic_bytes(G, args.batch)
-        fl_ms = timer.total_ms('filtered_lrelu') / max(ksteps, 1)        # per step, all 15 launches
-        conv_ms = timer.total_ms('modulated_conv2d') / max(ksteps, 1)
+        n_layers = len(G.synthesis.layer_names)
+        fl_ms = timer.median_step_ms('filtered_lrelu', n_layers)         # per step, all 15 launches
+        conv_ms = timer.median_step_ms('modulated_conv2d', n_layers)
         achieved = total_bytes / (fl_ms * 1e-3) / 1e9 if fl_ms > 0 else 0.0
         # HBM traffic of the same 15 launches from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes over this
         # command, summarised by tools/sum_traffic.py); only valid for the default workload

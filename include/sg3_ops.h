@@ -101,8 +101,8 @@ typedef struct sg3_filtered_lrelu_params {
     int32_t        flip;       /* 1 = correlation (flip_filter=True) */
     int32_t        writeSigns;
     int32_t        readSigns;
-    float*         ySumPartial; /* optional [N*C, sg3_filtered_lrelu_sum_slots(...)]: per-workgroup sums of the outputs of each
-                                 * plane (fused kernels only).  The caller adds them up: the bias gradient db = dx.sum([0,2,3])
+    float*         ySumPartial; /* optional, readSigns calls only: [N*C, sg3_filtered_lrelu_sum_slots(...)] per-workgroup sums of
+                                 * the outputs of each plane.  The caller adds them up: the bias gradient db = dx.sum([0,2,3])
                                  * of the adjoint pass (torch_utils/ops/filtered_lrelu.py:266-267) without re-reading dx */
 } sg3_filtered_lrelu_params;
 

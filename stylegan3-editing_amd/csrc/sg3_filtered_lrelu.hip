@@ -58,7 +58,7 @@ struct StreamParams {
     int totalBlocks;
     float gain, slope, clamp;
     int flip;
-    float* ysum;                   // optional [N*C][nChunks*nStrips]: sum of this block's outputs (bias gradient of the adjoint pass)
+    float* ysum;                   // optional [N*C][nChunks*nStrips]: sum of this block's outputs (adjoint passes only: their bias gradient)
     unsigned char* s;              // sign tensor [N*C][sH][sWb] (2 bits per upsampled sample, 4 per byte), or null
     int sH, sWb, sx, sy;           // rows, bytes per row, offset of the upsampled buffer inside the sign tensor
 };
@@ -417,7 +417,7 @@ struct Stream {
                     if (oy >= oy0 && oy < oy1) {                   // wave-uniform
                         const v2f y0 = st.acc[headR][0], y1 = st.acc[headR][1];
                         const float f0 = (y0.x + y0.y) * gainOut, f1 = (y1.x + y1.y) * gainOut;
-                        st.osum += (2 * lane < oxN ? f0 : 0.f) + (2 * lane + 1 < oxN ? f1 : 0.f);
+                        if (SIGNS == 2) st.osum += (2 * lane < oxN ? f0 : 0.f) + (2 * lane + 1 < oxN ? f1 : 0.f);
                         T* orow = oplane + (long long)oy * p.ysH + ox0;
                         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)orow, (short)0, oxN * (int)sizeof(T), 0x00020000);
                         if (pairStore) {
@@ -467,7 +467,7 @@ struct Stream {
 #pragma unroll
                         for (int q = 1; q < Cfg::FD / 2; q++) { y0 = fma2(pr[q], st.tdP[q], y0); y1 = fma2(pr[q + 1], st.tdP[q], y1); }
                         const float f0 = (y0.x + y0.y) * gainOut, f1 = (y1.x + y1.y) * gainOut;
-                        st.osum += (2 * lane < oxN ? f0 : 0.f) + (2 * lane + 1 < oxN ? f1 : 0.f);
+                        if (SIGNS == 2) st.osum += (2 * lane < oxN ? f0 : 0.f) + (2 * lane + 1 < oxN ? f1 : 0.f);
                         if (pairStore) {
                             bufio<T>::st2(rs, 2 * lane * (int)sizeof(T), f0, f1);
                         } else {
@@ -483,7 +483,7 @@ struct Stream {
 #pragma unroll
                         for (int q = 1; q < Cfg::FD / 2; q++) y0 = fma2(pr[q], st.tdP[q], y0);
                         const float f0 = (y0.x + y0.y) * gainOut;
-                        st.osum += lane < oxN ? f0 : 0.f;
+                        if (SIGNS == 2) st.osum += lane < oxN ? f0 : 0.f;
                         bufio<T>::st1(rs, lane * (int)sizeof(T), f0);
                     }
                     wave_lds_sync();
@@ -600,7 +600,7 @@ struct Stream {
                     for (int h = 0; h < 2; h++) { const v2f t = st.acc[r][h]; st.acc[r][h] = st.acc[r + 3][h]; st.acc[r + 3][h] = t; }
             }
         }
-        if (p.ysum) {
+        if (SIGNS == 2 && p.ysum) {                         // bias gradient of the adjoint pass
             float v = st.osum;
 #pragma unroll
             for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
