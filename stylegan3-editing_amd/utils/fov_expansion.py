@@ -35,13 +35,19 @@ class Expander:
         lt = np.broadcast_to(landmark_t, (n, 3, 3)) if landmark_t.ndim == 2 else landmark_t
         # sample-major inside each tile: batch index = tile * n + sample
         tr = np.stack([lt[j] @ transforms[i] for i in live for j in range(n)])
+        # the per-sample tile transforms are put back afterwards: a [B*T,3,3] buffer left behind would break the next
+        # caller's batch size (the reference leaves its last [3,3] tile transform in place)
+        previous = G.synthesis.input.transform
         G.synthesis.input.transform = torch.from_numpy(tr).float().to(device)
         rep = len(live)
-        with torch.no_grad():
-            if all_s is not None:
-                imgs = G.synthesis(None, {k: v.repeat(rep, *([1] * (v.ndim - 1))) for k, v in all_s.items()}, **self.synthesis_kwargs)
-            else:
-                imgs = G.synthesis(ws.repeat(rep, 1, 1), None, **self.synthesis_kwargs)
+        try:
+            with torch.no_grad():
+                if all_s is not None:
+                    imgs = G.synthesis(None, {k: v.repeat(rep, *([1] * (v.ndim - 1))) for k, v in all_s.items()}, **self.synthesis_kwargs)
+                else:
+                    imgs = G.synthesis(ws.repeat(rep, 1, 1), None, **self.synthesis_kwargs)
+        finally:
+            G.synthesis.input.transform = previous
         images = [None] * len(transforms)
         for k, i in enumerate(live):
             images[i] = imgs[k * n:(k + 1) * n]
