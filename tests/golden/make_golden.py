@@ -209,11 +209,33 @@ def gen_big():
     np.savez_compressed(os.path.join(HERE, 'net_t1024_stats.npz'), **out)
 
 
+def gen_big_r():
+    """Full-size config-R forwards (the reference's default generator branch, models/stylegan3/model.py:42-54): R-512
+    (BASELINE configs[4]) and R-1024 (the inversion / PTI decoder), batch 1, samples and statistics only."""
+    out = {}
+    t0 = time.time()
+    for cfg in ['R512', 'R1024']:
+        G = load_synth(Generator(**CONFIGS[cfg]), cfg)
+        ws = T(synth_ws(1, G.num_ws, G.w_dim, seed=1))
+        img, feats = layer_feats(G, ws)
+        res = G.img_resolution
+        out[f'{cfg}/stats'] = np.asarray([[f.mean().item(), f.std().item(), f.abs().max().item()] for f in feats], np.float64)
+        out[f'{cfg}/img_stats'] = np.asarray([img.mean().item(), img.std().item(), img.abs().max().item()], np.float64)
+        out[f'{cfg}/img_sub'] = img[:, :, ::16, ::16].numpy()
+        out[f'{cfg}/img_rows'] = img[:, :, [0, res // 2 - 1, res - 1], :].numpy()
+        for n, f in zip(G.synthesis.layer_names, feats):
+            out[f'{cfg}/corner/{n}'] = f[:, :2, :32, :32].numpy()
+            out[f'{cfg}/center/{n}'] = f[:, -1:, f.shape[2] // 2, :].numpy()
+        print(cfg, 'done', time.time() - t0)
+        del G
+    np.savez_compressed(os.path.join(HERE, 'net_r_stats.npz'), **out)
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default=None)
     a = ap.parse_args()
-    steps = dict(filters=gen_filters, manifest=gen_manifest, ops=gen_ops, grads=gen_grads, net=gen_net_tiny, big=gen_big)
+    steps = dict(filters=gen_filters, manifest=gen_manifest, ops=gen_ops, grads=gen_grads, net=gen_net_tiny, big=gen_big, big_r=gen_big_r)
     for k, fn in steps.items():
         if a.only is None or a.only == k:
             fn()

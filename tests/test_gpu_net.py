@@ -130,3 +130,27 @@ def test_graphed_synthesis_replay_equals_eager():
         all_s = G.synthesis.W2S(ws)
         gs = GraphedSynthesis(G, 2, all_s_template=all_s)
         assert torch.equal(gs(all_s=all_s).clone(), G.synthesis(None, all_s=all_s, noise_mode='const', force_fp32=True))
+
+
+@pytest.mark.parametrize('cfg', ['R512', 'R1024'])
+def test_config_r_full_size_against_reference_samples(cfg):
+    """Config R at full size (1x1 split-precision GEMM, radial streaming filtered_lrelu): per-layer corner / centre
+    samples, strided image subsample, three full rows and global statistics of the reference's forward."""
+    g = golden('net_r_stats')
+    G = build_product_generator(cfg, device=DEV)
+    ws = T(synth_ws(1, G.num_ws, G.w_dim, seed=1))
+    feats = []
+    hooks = [getattr(G.synthesis, n).register_forward_hook(lambda m, i, o: feats.append(o)) for n in G.synthesis.layer_names]
+    with torch.no_grad():
+        img = G.synthesis(ws, noise_mode='const', force_fp32=True)
+    for h in hooks:
+        h.remove()
+    res = G.img_resolution
+    for n, f in zip(G.synthesis.layer_names, feats):
+        assert maxabs(f[:1, :2, :32, :32].cpu().numpy(), g[f'{cfg}/corner/{n}']) <= 2e-4, n
+        assert maxabs(f[:1, -1:, f.shape[2] // 2, :].cpu().numpy(), g[f'{cfg}/center/{n}']) <= 2e-4, n
+    stats = np.asarray([[f[:1].mean().item(), f[:1].std().item(), f[:1].abs().max().item()] for f in feats])
+    assert np.abs(stats - g[f'{cfg}/stats']).max() <= 2e-3
+    assert maxabs(img[:1, :, ::16, ::16].cpu().numpy(), g[f'{cfg}/img_sub']) <= 1e-4
+    assert maxabs(img[:1, :, [0, res // 2 - 1, res - 1], :].cpu().numpy(), g[f'{cfg}/img_rows']) <= 1e-4
+    assert abs(img[:1].mean().item() - g[f'{cfg}/img_stats'][0]) <= 1e-5
