@@ -171,3 +171,39 @@ def test_sharded_sweep_matches_single_process(tmp_path):
     mp.spawn(_sweep_worker, args=(2, port, str(tmp_path), paths), nprocs=2, join=True)
     a, b = np.load(tmp_path / 'sweep_0.npy'), np.load(tmp_path / 'sweep_1.npy')
     assert np.array_equal(a, b) and maxabs(a, ref) <= 1e-5
+
+
+def _pp_worker(rank, world, port, out_dir, paths):
+    for p in paths:
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from inversion.video import post_processing as pp
+    G = build_product_generator('Ttiny')
+    lat = synth_ws(7, G.num_ws, G.w_dim, seed=9)
+    results = {'result_latents': {f'{i:04d}': lat[i] for i in range(7)}, 'landmarks_transforms': [None] * 7}
+    opts = types.SimpleNamespace(expansion_amounts=[4, 2, 0, 3], landmarks_transforms_path=None)
+    frames = pp.postprocess_and_smooth_inversions(results, types.SimpleNamespace(decoder=G), opts, frames_per_batch=2, shard=True)
+    np.save(os.path.join(out_dir, f'frames_{rank}.npy'), np.stack(frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_frame_rendering_matches_single_process(tmp_path):
+    """world_size 2 over gloo: the 3 smoothed frames of a 7-frame clip are rendered 2 + 1; concatenated in rank order they
+    equal the single-process frames."""
+    from inversion.video import post_processing as pp
+    G = build_product_generator('Ttiny')
+    lat = synth_ws(7, G.num_ws, G.w_dim, seed=9)
+    results = {'result_latents': {f'{i:04d}': lat[i] for i in range(7)}, 'landmarks_transforms': [None] * 7}
+    opts = types.SimpleNamespace(expansion_amounts=[4, 2, 0, 3], landmarks_transforms_path=None)
+    ref = np.stack(pp.postprocess_and_smooth_inversions(results, types.SimpleNamespace(decoder=G), opts, frames_per_batch=3))
+    paths = [p for p in sys.path if 'stylegan3-editing_amd' in p or p.endswith('tests') or p.endswith('repo')]
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_pp_worker, args=(2, port, str(tmp_path), paths), nprocs=2, join=True)
+    a, b = np.load(tmp_path / 'frames_0.npy'), np.load(tmp_path / 'frames_1.npy')
+    assert a.shape[0] == 2 and b.shape[0] == 1
+    got = np.concatenate([a, b])
+    assert got.shape == ref.shape and np.abs(got.astype(np.int32) - ref.astype(np.int32)).max() <= 1
