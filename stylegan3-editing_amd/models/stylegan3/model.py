@@ -5,8 +5,8 @@ Weight-layout contract kept from the reference: a `.pkl` is `pickle.load(f)['G_e
 embedded NVIDIA module source is exec'd against this package's `torch_utils` / `dnnlib`, so it runs on the HIP
 kernels); anything else is a plain `Generator.state_dict()` loaded strictly, or -- if that fails -- without the
 `synthesis.input.transform` entry (:59-65).  `config="landscape"` selects the config-T sizes (:29-40), everything
-else config-R (:42-54).  Unlike the reference, `device=` is explicit and the module is moved to the GPU for every
-branch, not only for pickles.
+else config-R (:42-54).  `device=` replaces the reference's hard-coded `.cuda()` on the pickle branch; a generator built
+from a state dict stays on the CPU until the caller moves it, as in the reference.
 """
 import pickle
 from enum import Enum
@@ -17,10 +17,13 @@ import torch
 
 from models.stylegan3.networks_stylegan3 import Generator
 
-CONFIG_T = dict(z_dim=512, c_dim=0, w_dim=512, img_channels=3, channel_base=32768, channel_max=512,
-                magnitude_ema_beta=0.9988915792636801, mapping_kwargs={'num_layers': 2})
-CONFIG_R = dict(z_dim=512, c_dim=0, w_dim=512, img_channels=3, channel_base=65536, channel_max=1024, conv_kernel=1,
-                filter_size=6, magnitude_ema_beta=0.9988915792636801, output_scale=0.25, use_radial_filters=True)
+_COMMON = dict(z_dim=512, c_dim=0, w_dim=512, img_channels=3, magnitude_ema_beta=0.5 ** (32 / (20 * 1e3)))
+# translation-equivariant config: 3x3 convs, separable 12-tap filters, two mapping layers in the landscape checkpoints
+CONFIG_T = dict(_COMMON, channel_base=32768, channel_max=512, mapping_kwargs={'num_layers': 2})
+# rotation-equivariant config: 1x1 convs, radial 6-tap filters, twice the channels at a quarter of the output scale
+CONFIG_R = dict(_COMMON, channel_base=65536, channel_max=1024, conv_kernel=1, filter_size=6, output_scale=0.25,
+                use_radial_filters=True)
+_SHAPE_DEPENDENT = 'synthesis.input.transform'
 
 
 class GeneratorType(str, Enum):
@@ -31,25 +34,29 @@ class GeneratorType(str, Enum):
         return str(self.value)
 
 
+def _from_pickle(path, device):
+    with open(path, 'rb') as fh:
+        return pickle.load(fh)['G_ema'].to(device)
+
+
+def _from_state_dict(net, path):
+    state = torch.load(path, map_location='cpu')
+    try:
+        net.load_state_dict(state, strict=True)
+    except RuntimeError:
+        # checkpoints saved after a batched call carry a [B,3,3] transform buffer
+        net.load_state_dict({k: v for k, v in state.items() if _SHAPE_DEPENDENT not in k}, strict=False)
+    return net
+
+
 class SG3Generator(torch.nn.Module):
     def __init__(self, checkpoint_path: Optional[Path] = None, res: int = 1024, config: str = None, device='cuda'):
         super().__init__()
         print(f"Loading StyleGAN3 generator from path: {checkpoint_path}")
         if str(checkpoint_path).endswith("pkl"):
-            with open(checkpoint_path, "rb") as f:
-                self.decoder = pickle.load(f)['G_ema'].to(device)
-            print('Done!')
-            return
-        kwargs = CONFIG_T if config == "landscape" else CONFIG_R
-        self.decoder = Generator(img_resolution=res, **kwargs)
-        if checkpoint_path is not None:
-            self._load_checkpoint(checkpoint_path)
+            self.decoder = _from_pickle(checkpoint_path, device)
+        else:
+            self.decoder = Generator(img_resolution=res, **(CONFIG_T if config == "landscape" else CONFIG_R))
+            if checkpoint_path is not None:
+                _from_state_dict(self.decoder, checkpoint_path)
         print('Done!')
-
-    def _load_checkpoint(self, checkpoint_path):
-        ckpt = torch.load(checkpoint_path, map_location='cpu')
-        try:
-            self.decoder.load_state_dict(ckpt, strict=True)
-        except RuntimeError:
-            ckpt = {k: v for k, v in ckpt.items() if "synthesis.input.transform" not in k}
-            self.decoder.load_state_dict(ckpt, strict=False)

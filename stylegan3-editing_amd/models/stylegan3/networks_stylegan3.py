@@ -28,7 +28,26 @@ from torch_utils import misc, persistence
 from torch_utils.ops import bias_act, filtered_lrelu
 from torch_utils.ops import modulated_conv as _modconv
 
-# ----------------------------------------------------------------------------
+
+
+def _keep(module, **fields):
+    """Store constructor arguments as plain attributes (they are part of the pickled state and of the public surface)."""
+    for name, value in fields.items():
+        setattr(module, name, value)
+
+
+def _xy(value):
+    return np.broadcast_to(np.asarray(value), [2])
+
+
+def _summary(module, *rows):
+    """extra_repr text: one line per row of attribute names; floats in %g, sizes as lists, the rest via str()."""
+    def show(name):
+        v = getattr(module, name)
+        if isinstance(v, np.ndarray):
+            return f'{name}={[int(e) for e in v]}'
+        return f'{name}={v:g}' if isinstance(v, (float, np.floating)) else f'{name}={v}'
+    return '\n'.join(', '.join(show(n) for n in row.split()) + (',' if i + 1 < len(rows) else '') for i, row in enumerate(rows))
 
 
 @misc.profiled_function
@@ -40,7 +59,6 @@ def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, x_bou
     its split-precision matrix-core path (torch_utils/ops/modulated_conv.py)."""
     return _modconv.modulated_conv2d(x, w, s, demodulate=demodulate, padding=padding, input_gain=input_gain, x_bound=x_bound)
 
-# ----------------------------------------------------------------------------
 
 
 @persistence.persistent_class
@@ -49,30 +67,28 @@ class FullyConnectedLayer(torch.nn.Module):
 
     def __init__(self, in_features, out_features, activation='linear', bias=True, lr_multiplier=1, weight_init=1, bias_init=0):
         super().__init__()
-        self.in_features = in_features
-        self.out_features = out_features
-        self.activation = activation
+        _keep(self, in_features=in_features, out_features=out_features, activation=activation,
+              weight_gain=lr_multiplier / np.sqrt(in_features), bias_gain=lr_multiplier)
         self.weight = torch.nn.Parameter(torch.randn([out_features, in_features]) * (weight_init / lr_multiplier))
         b0 = np.broadcast_to(np.asarray(bias_init, dtype=np.float32), [out_features])
         self.bias = torch.nn.Parameter(torch.from_numpy(b0 / lr_multiplier)) if bias else None
-        self.weight_gain = lr_multiplier / np.sqrt(in_features)
-        self.bias_gain = lr_multiplier
+
+    def _scaled(self, dtype):
+        w = self.weight.to(dtype) * self.weight_gain
+        if self.bias is None:
+            return w, None
+        b = self.bias.to(dtype)
+        return w, (b if self.bias_gain == 1 else b * self.bias_gain)
 
     def forward(self, x):
-        w = self.weight.to(x.dtype) * self.weight_gain
-        b = self.bias
-        if b is not None:
-            b = b.to(x.dtype)
-            if self.bias_gain != 1:
-                b = b * self.bias_gain
-        if self.activation == 'linear' and b is not None:
+        w, b = self._scaled(x.dtype)
+        if b is not None and self.activation == 'linear':
             return torch.addmm(b.unsqueeze(0), x, w.t())
         return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
 
     def extra_repr(self):
-        return f'in_features={self.in_features:d}, out_features={self.out_features:d}, activation={self.activation:s}'
+        return _summary(self, 'in_features out_features activation')
 
-# ----------------------------------------------------------------------------
 
 
 @persistence.persistent_class
@@ -81,12 +97,7 @@ class MappingNetwork(torch.nn.Module):
 
     def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=2, lr_multiplier=0.01, w_avg_beta=0.998):
         super().__init__()
-        self.z_dim = z_dim
-        self.c_dim = c_dim
-        self.w_dim = w_dim
-        self.num_ws = num_ws
-        self.num_layers = num_layers
-        self.w_avg_beta = w_avg_beta
+        _keep(self, z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=num_ws, num_layers=num_layers, w_avg_beta=w_avg_beta)
         self.embed = FullyConnectedLayer(c_dim, w_dim) if c_dim > 0 else None
         widths = [z_dim + (w_dim if c_dim > 0 else 0)] + [w_dim] * num_layers
         for i in range(num_layers):
@@ -114,9 +125,8 @@ class MappingNetwork(torch.nn.Module):
         return ws
 
     def extra_repr(self):
-        return f'z_dim={self.z_dim:d}, c_dim={self.c_dim:d}, w_dim={self.w_dim:d}, num_ws={self.num_ws:d}'
+        return _summary(self, 'z_dim c_dim w_dim num_ws')
 
-# ----------------------------------------------------------------------------
 
 
 @persistence.persistent_class
@@ -126,15 +136,12 @@ class SynthesisInput(torch.nn.Module):
 
     def __init__(self, w_dim, channels, size, sampling_rate, bandwidth):
         super().__init__()
-        self.w_dim = w_dim
-        self.channels = channels
-        self.size = np.broadcast_to(np.asarray(size), [2])
-        self.sampling_rate = sampling_rate
-        self.bandwidth = bandwidth
+        _keep(self, w_dim=w_dim, channels=channels, size=_xy(size), sampling_rate=sampling_rate, bandwidth=bandwidth)
 
+        # directions uniform on the circle, radii distributed so that the spectrum is flat inside the band limit
         freqs = torch.randn([channels, 2])
-        radii = freqs.square().sum(dim=1, keepdim=True).sqrt()
-        freqs = freqs / (radii * radii.square().exp().pow(0.25)) * bandwidth
+        r = freqs.norm(dim=1, keepdim=True)
+        freqs = freqs / (r * r.square().exp().pow(0.25)) * bandwidth
         phases = torch.rand([channels]) - 0.5
 
         self.weight = torch.nn.Parameter(torch.randn([channels, channels]))
@@ -186,11 +193,8 @@ class SynthesisInput(torch.nn.Module):
         return x
 
     def extra_repr(self):
-        return '\n'.join([
-            f'w_dim={self.w_dim:d}, channels={self.channels:d}, size={list(self.size)},',
-            f'sampling_rate={self.sampling_rate:g}, bandwidth={self.bandwidth:g}'])
+        return _summary(self, 'w_dim channels size', 'sampling_rate bandwidth')
 
-# ----------------------------------------------------------------------------
 
 
 def design_lowpass_filter(numtaps, cutoff, width, fs, radial=False):
@@ -221,24 +225,13 @@ class SynthesisLayer(torch.nn.Module):
                  conv_kernel=3, filter_size=6, lrelu_upsampling=2, use_radial_filters=False, conv_clamp=256,
                  magnitude_ema_beta=0.999):
         super().__init__()
-        self.w_dim = w_dim
-        self.is_torgb = is_torgb
-        self.is_critically_sampled = is_critically_sampled
-        self.use_fp16 = use_fp16
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.in_size = np.broadcast_to(np.asarray(in_size), [2])
-        self.out_size = np.broadcast_to(np.asarray(out_size), [2])
-        self.in_sampling_rate = in_sampling_rate
-        self.out_sampling_rate = out_sampling_rate
-        self.tmp_sampling_rate = max(in_sampling_rate, out_sampling_rate) * (1 if is_torgb else lrelu_upsampling)
-        self.in_cutoff = in_cutoff
-        self.out_cutoff = out_cutoff
-        self.in_half_width = in_half_width
-        self.out_half_width = out_half_width
-        self.conv_kernel = 1 if is_torgb else conv_kernel
-        self.conv_clamp = conv_clamp
-        self.magnitude_ema_beta = magnitude_ema_beta
+        _keep(self, w_dim=w_dim, is_torgb=is_torgb, is_critically_sampled=is_critically_sampled, use_fp16=use_fp16,
+              in_channels=in_channels, out_channels=out_channels, in_size=_xy(in_size), out_size=_xy(out_size),
+              in_sampling_rate=in_sampling_rate, out_sampling_rate=out_sampling_rate,
+              in_cutoff=in_cutoff, out_cutoff=out_cutoff, in_half_width=in_half_width, out_half_width=out_half_width,
+              conv_kernel=(1 if is_torgb else conv_kernel), conv_clamp=conv_clamp, magnitude_ema_beta=magnitude_ema_beta,
+              # the non-linearity runs at `lrelu_upsampling` times the faster of the two rates (ToRGB has none)
+              tmp_sampling_rate=max(in_sampling_rate, out_sampling_rate) * (1 if is_torgb else lrelu_upsampling))
 
         self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
         self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, self.conv_kernel, self.conv_kernel]))
@@ -289,38 +282,38 @@ class SynthesisLayer(torch.nn.Module):
 
     def forward(self, x, w, styles=None, noise_mode='random', force_fp32=False, update_emas=False):
         assert noise_mode in ['random', 'const', 'none']  # kept for API compatibility; SG3 has no noise inputs
-        misc.assert_shape(x, [None, self.in_channels, int(self.in_size[1]), int(self.in_size[0])])
+        in_w, in_h = (int(v) for v in self.in_size)
+        out_w, out_h = (int(v) for v in self.out_size)
+        misc.assert_shape(x, [None, self.in_channels, in_h, in_w])
         if update_emas:
-            with torch.autograd.profiler.record_function('update_magnitude_ema'):
-                cur = x.detach().to(torch.float32).square().mean()
-                self.magnitude_ema.copy_(cur.lerp(self.magnitude_ema, self.magnitude_ema_beta))
+            self._track_magnitude(x)
         input_gain = self.magnitude_ema.rsqrt()
 
         if styles is None:
             misc.assert_shape(w, [x.shape[0], self.w_dim])
             styles = self.styles_from_w(w)
 
-        dtype = torch.float16 if (self.use_fp16 and not force_fp32 and x.device.type == 'cuda') else torch.float32
+        half = self.use_fp16 and not force_fp32 and x.device.type == 'cuda'
+        dtype = torch.float16 if half else torch.float32
         x = modulated_conv2d(x=x.to(dtype), w=self.weight, s=styles, padding=self.conv_kernel - 1,
                              demodulate=(not self.is_torgb), input_gain=input_gain, x_bound=getattr(self, 'input_bound', None))
         x = filtered_lrelu.filtered_lrelu(
             x=x, fu=self.up_filter, fd=self.down_filter, b=self.bias.to(x.dtype), up=self.up_factor, down=self.down_factor,
             padding=self.padding, gain=(1 if self.is_torgb else np.sqrt(2)), slope=(1 if self.is_torgb else 0.2), clamp=self.conv_clamp)
-        misc.assert_shape(x, [None, self.out_channels, int(self.out_size[1]), int(self.out_size[0])])
+        misc.assert_shape(x, [None, self.out_channels, out_h, out_w])
         assert x.dtype == dtype
         return x
 
-    def extra_repr(self):
-        return '\n'.join([
-            f'w_dim={self.w_dim:d}, is_torgb={self.is_torgb},',
-            f'is_critically_sampled={self.is_critically_sampled}, use_fp16={self.use_fp16},',
-            f'in_sampling_rate={self.in_sampling_rate:g}, out_sampling_rate={self.out_sampling_rate:g},',
-            f'in_cutoff={self.in_cutoff:g}, out_cutoff={self.out_cutoff:g},',
-            f'in_half_width={self.in_half_width:g}, out_half_width={self.out_half_width:g},',
-            f'in_size={list(self.in_size)}, out_size={list(self.out_size)},',
-            f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}'])
+    def _track_magnitude(self, x):
+        """Running mean of the input's power; its rsqrt is the gain that keeps the convolution input at unit variance."""
+        with torch.autograd.profiler.record_function('update_magnitude_ema'):
+            power = x.detach().to(torch.float32).square().mean()
+            self.magnitude_ema.copy_(power.lerp(self.magnitude_ema, self.magnitude_ema_beta))
 
-# ----------------------------------------------------------------------------
+    def extra_repr(self):
+        return _summary(self, 'w_dim is_torgb', 'is_critically_sampled use_fp16', 'in_sampling_rate out_sampling_rate',
+                        'in_cutoff out_cutoff', 'in_half_width out_half_width', 'in_size out_size', 'in_channels out_channels')
+
 
 LayerGeometry = collections.namedtuple('LayerGeometry', [
     'index', 'is_torgb', 'is_critically_sampled', 'use_fp16', 'in_channels', 'out_channels', 'in_size', 'out_size',
@@ -363,15 +356,9 @@ class SynthesisNetwork(torch.nn.Module):
                  num_critical=2, first_cutoff=2, first_stopband=2 ** 2.1, last_stopband_rel=2 ** 0.3, margin_size=10,
                  output_scale=0.25, num_fp16_res=4, **layer_kwargs):
         super().__init__()
-        self.w_dim = w_dim
-        self.num_ws = num_layers + 2
-        self.img_resolution = img_resolution
-        self.img_channels = img_channels
-        self.num_layers = num_layers
-        self.num_critical = num_critical
-        self.margin_size = margin_size
-        self.output_scale = output_scale
-        self.num_fp16_res = num_fp16_res
+        _keep(self, w_dim=w_dim, num_ws=num_layers + 2, img_resolution=img_resolution, img_channels=img_channels,
+              num_layers=num_layers, num_critical=num_critical, margin_size=margin_size, output_scale=output_scale,
+              num_fp16_res=num_fp16_res)
 
         input_spec, table = synthesis_schedule(
             img_resolution, img_channels, channel_base=channel_base, channel_max=channel_max, num_layers=num_layers,
@@ -427,24 +414,15 @@ class SynthesisNetwork(torch.nn.Module):
         return all_s
 
     def extra_repr(self):
-        return '\n'.join([
-            f'w_dim={self.w_dim:d}, num_ws={self.num_ws:d},',
-            f'img_resolution={self.img_resolution:d}, img_channels={self.img_channels:d},',
-            f'num_layers={self.num_layers:d}, num_critical={self.num_critical:d},',
-            f'margin_size={self.margin_size:d}, num_fp16_res={self.num_fp16_res:d}'])
+        return _summary(self, 'w_dim num_ws', 'img_resolution img_channels', 'num_layers num_critical', 'margin_size num_fp16_res')
 
-# ----------------------------------------------------------------------------
 
 
 @persistence.persistent_class
 class Generator(torch.nn.Module):
     def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, **synthesis_kwargs):
         super().__init__()
-        self.z_dim = z_dim
-        self.c_dim = c_dim
-        self.w_dim = w_dim
-        self.img_resolution = img_resolution
-        self.img_channels = img_channels
+        _keep(self, z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels)
         self.synthesis = SynthesisNetwork(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
         self.num_ws = self.synthesis.num_ws
         self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, **mapping_kwargs)

@@ -6,6 +6,10 @@ and name `torch_utils.persistence._reconstruct_persistent_obj` as the unpickling
 torch_utils/persistence.py:119-127, 180-203).  Unpickling therefore execs the embedded NVIDIA module source, which
 imports `torch_utils.misc`, `torch_utils.persistence`, `torch_utils.ops.*` and `dnnlib` BY THOSE NAMES -- that is
 what makes this package layout part of the drop-in contract: the embedded graph code then runs on the HIP kernels.
+
+Layout of this module: `_Sources` is the two-way registry module <-> source text; `_PersistentMixin` carries the
+behaviour (remembered constructor arguments, `__reduce__` in the wire format above) and `persistent_class` derives
+`type(name, (_PersistentMixin, cls), ...)` from the decorated class.
 """
 import copy
 import inspect
@@ -17,11 +21,66 @@ import uuid
 
 import dnnlib
 
-_version = 6
-_decorators = set()
-_import_hooks = []
-_module_to_src_dict = {}
-_src_to_module_dict = {}
+_version = 6            # wire-format version written into / required from every record
+_import_hooks = []      # callables meta -> meta applied while unpickling
+
+
+class _Sources:
+    """Two-way map between live modules and their source text; unseen source text is exec'd into a fresh module."""
+
+    def __init__(self):
+        self.text_of = {}
+        self.module_of = {}
+
+    def _bind(self, module, text):
+        self.text_of[module] = text
+        self.module_of[text] = module
+
+    def text(self, module):
+        if module not in self.text_of:
+            self._bind(module, inspect.getsource(module))
+        return self.text_of[module]
+
+    def module(self, text):
+        if text not in self.module_of:
+            mod = types.ModuleType('_imported_module_' + uuid.uuid4().hex)
+            sys.modules[mod.__name__] = mod
+            self._bind(mod, text)
+            exec(text, mod.__dict__)  # pylint: disable=exec-used
+        return self.module_of[text]
+
+
+_sources = _Sources()
+_module_to_src = _sources.text          # names used by the reference's legacy loader
+_src_to_module = _sources.module
+_derived = set()                        # every class produced by `persistent_class`
+
+
+class _PersistentMixin:
+    _orig_module_src = None
+    _orig_class_name = None
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._init_args = copy.deepcopy(args)
+        self._init_kwargs = copy.deepcopy(kwargs)
+        _check_pickleable(self.__reduce__())
+
+    @property
+    def init_args(self):
+        return copy.deepcopy(self._init_args)
+
+    @property
+    def init_kwargs(self):
+        return dnnlib.EasyDict(copy.deepcopy(self._init_kwargs))
+
+    def __reduce__(self):
+        func, args, state, *rest = (*super().__reduce__(), None, None)[:5]
+        if func is _reconstruct_persistent_obj:         # a base class is persistent too: already in wire format
+            return (func, args, state, *rest)
+        record = dict(type='class', version=_version, module_src=self._orig_module_src,
+                      class_name=self._orig_class_name, state=state)
+        return (_reconstruct_persistent_obj, (record,), None, *rest)
 
 
 def persistent_class(orig_class):
@@ -30,51 +89,22 @@ def persistent_class(orig_class):
     assert isinstance(orig_class, type)
     if is_persistent(orig_class):
         return orig_class
-    assert orig_class.__module__ in sys.modules
-    module = sys.modules[orig_class.__module__]
-    module_src = _module_to_src(module)
-
-    class Decorator(orig_class):
-        _orig_module_src = module_src
-        _orig_class_name = orig_class.__name__
-
-        def __init__(self, *args, **kwargs):
-            super().__init__(*args, **kwargs)
-            self._init_args = copy.deepcopy(args)
-            self._init_kwargs = copy.deepcopy(kwargs)
-            assert orig_class.__name__ in module.__dict__
-            _check_pickleable(self.__reduce__())
-
-        @property
-        def init_args(self):
-            return copy.deepcopy(self._init_args)
-
-        @property
-        def init_kwargs(self):
-            return dnnlib.EasyDict(copy.deepcopy(self._init_kwargs))
-
-        def __reduce__(self):
-            fields = list(super().__reduce__())
-            fields += [None] * max(3 - len(fields), 0)
-            if fields[0] is not _reconstruct_persistent_obj:
-                meta = dict(type='class', version=_version, module_src=self._orig_module_src,
-                            class_name=self._orig_class_name, state=fields[2])
-                fields[0], fields[1], fields[2] = _reconstruct_persistent_obj, (meta,), None
-            return tuple(fields)
-
-    Decorator.__name__ = orig_class.__name__
-    Decorator.__qualname__ = orig_class.__qualname__
-    _decorators.add(Decorator)
-    return Decorator
+    home = sys.modules[orig_class.__module__]
+    derived = type(orig_class.__name__, (_PersistentMixin, orig_class), dict(
+        _orig_module_src=_sources.text(home), _orig_class_name=orig_class.__name__,
+        __module__=orig_class.__module__, __qualname__=orig_class.__qualname__, __doc__=orig_class.__doc__))
+    _derived.add(derived)
+    return derived
 
 
 def is_persistent(obj):
+    """True for a class made by `persistent_class` and for instances of one."""
     try:
-        if obj in _decorators:
+        if obj in _derived:
             return True
-    except TypeError:
+    except TypeError:       # unhashable instance
         pass
-    return type(obj) in _decorators
+    return type(obj) in _derived
 
 
 def import_hook(hook):
@@ -85,59 +115,38 @@ def import_hook(hook):
 
 
 def _reconstruct_persistent_obj(meta):
+    """Unpickling entry point named inside the pickles: rebuild the class from its source, then restore the state."""
     meta = dnnlib.EasyDict(meta)
     meta.state = dnnlib.EasyDict(meta.state)
     for hook in _import_hooks:
         meta = hook(meta)
         assert meta is not None
-    assert meta.version == _version
-    module = _src_to_module(meta.module_src)
-    assert meta.type == 'class'
-    cls = persistent_class(module.__dict__[meta.class_name])
+    assert meta.version == _version and meta.type == 'class'
+    cls = persistent_class(getattr(_sources.module(meta.module_src), meta.class_name))
     obj = cls.__new__(cls)
-    setstate = getattr(obj, '__setstate__', None)
-    if callable(setstate):
-        setstate(meta.state)
+    restore = getattr(obj, '__setstate__', None)
+    if callable(restore):
+        restore(meta.state)
     else:
-        obj.__dict__.update(meta.state)
+        vars(obj).update(meta.state)
     return obj
 
 
-def _module_to_src(module):
-    src = _module_to_src_dict.get(module)
-    if src is None:
-        src = inspect.getsource(module)
-        _module_to_src_dict[module] = src
-        _src_to_module_dict[src] = module
-    return src
-
-
-def _src_to_module(src):
-    module = _src_to_module_dict.get(src)
-    if module is None:
-        name = '_imported_module_' + uuid.uuid4().hex
-        module = types.ModuleType(name)
-        sys.modules[name] = module
-        _module_to_src_dict[module] = src
-        _src_to_module_dict[src] = module
-        exec(src, module.__dict__)  # pylint: disable=exec-used
-    return module
+_PLAIN = (str, int, float, bool, bytes, bytearray, type(None))
+_ARRAYS = ('numpy.ndarray', 'torch.Tensor', 'torch.nn.parameter.Parameter')
 
 
 def _check_pickleable(obj):
-    """Cheap structural check that obj can be pickled (containers, primitives, tensors, persistent objects,
-    functions); anything else is test-pickled for real."""
-    def strip(o):
-        if isinstance(o, (list, tuple, set)):
-            return [strip(x) for x in o]
+    """Fail early (at construction) when something in `obj` cannot be pickled.  Containers are walked; primitives,
+    arrays / tensors, persistent objects, functions and classes are accepted as they are; whatever remains is
+    test-pickled for real."""
+    def residue(o):
         if isinstance(o, dict):
-            return [[strip(k), strip(v)] for k, v in o.items()]
-        if isinstance(o, (str, int, float, bool, bytes, bytearray)) or o is None:
-            return None
-        if f'{type(o).__module__}.{type(o).__name__}' in ('numpy.ndarray', 'torch.Tensor', 'torch.nn.parameter.Parameter'):
-            return None
-        if is_persistent(o) or inspect.isfunction(o) or inspect.isclass(o):
+            return [[residue(k), residue(v)] for k, v in o.items()]
+        if isinstance(o, (list, tuple, set)):
+            return [residue(v) for v in o]
+        kind = f'{type(o).__module__}.{type(o).__name__}'
+        if isinstance(o, _PLAIN) or kind in _ARRAYS or is_persistent(o) or inspect.isfunction(o) or inspect.isclass(o):
             return None
         return o
-    with io.BytesIO() as f:
-        pickle.dump(strip(obj), f)
+    pickle.dump(residue(obj), io.BytesIO())

@@ -1,15 +1,19 @@
-"""Transform helpers of the reference's utils/common.py:9-45 that the inversion path uses (tensor2im / mp4 writing need
-PIL / imageio and belong to the out-of-scope I/O layer)."""
+"""Input-transform helpers used by the inversion path (reference utils/common.py:9-45; tensor2im / mp4 writing need PIL /
+imageio and belong to the out-of-scope I/O layer).
+
+A transform is the 3x3 matrix that `SynthesisInput` receives in `synthesis.input.transform`: the INVERSE of "rotate by
+`angle` degrees, then shift by `translate`" in the generator's [-1, 1] canvas units."""
 import numpy as np
 
 
 def make_transform(translate, angle):
-    m = np.eye(3)
-    s = np.sin(angle / 360.0 * np.pi * 2)
-    c = np.cos(angle / 360.0 * np.pi * 2)
-    m[0][0], m[0][1], m[0][2] = c, s, translate[0]
-    m[1][0], m[1][1], m[1][2] = -s, c, translate[1]
-    return m
+    """Forward matrix [[c, s, tx], [-s, c, ty], [0, 0, 1]] for `angle` in degrees (expression order of the reference, so
+    that the float64 result is bit-identical)."""
+    theta = angle / 360.0 * np.pi * 2
+    c, s = np.cos(theta), np.sin(theta)
+    return np.array([[c, s, translate[0]],
+                     [-s, c, translate[1]],
+                     [0.0, 0.0, 1.0]])
 
 
 def get_identity_transform():
@@ -17,6 +21,8 @@ def get_identity_transform():
 
 
 def generate_random_transform(translate=0.3, rotate=25):
-    rotate = np.random.uniform(low=-1 * rotate, high=rotate)
-    translate = (np.random.uniform(low=-1 * translate, high=translate), np.random.uniform(low=-1 * translate, high=translate))
-    return np.linalg.inv(make_transform(translate, rotate))
+    """Uniform angle in +-rotate degrees and uniform shift in +-translate, drawn from numpy's global stream in the
+    reference's order (angle, x, y)."""
+    angle = np.random.uniform(-rotate, rotate)
+    shift = np.random.uniform(-translate, translate, size=2)
+    return np.linalg.inv(make_transform(shift, angle))
