@@ -104,6 +104,10 @@ typedef struct sg3_filtered_lrelu_params {
     float*         ySumPartial; /* optional, readSigns calls only: [N*C, sg3_filtered_lrelu_sum_slots(...)] per-workgroup sums of
                                  * the outputs of each plane.  The caller adds them up: the bias gradient db = dx.sum([0,2,3])
                                  * of the adjoint pass (torch_utils/ops/filtered_lrelu.py:266-267) without re-reading dx */
+    int32_t        fdMirror;    /* caller's promise about a 2-D down filter: fd[r][c] == fd[r][fdW-1-c] bit for bit (true of the
+                                 * radial filters design_lowpass_filter builds, networks_stylegan3.py:370-391).  The kernel then
+                                 * adds the two samples that share a tap before multiplying: 42 instead of 72 packed operations per
+                                 * upsampled row and lane.  0 = no assumption */
 } sg3_filtered_lrelu_params;
 
 SG3_API int sg3_filtered_lrelu(const sg3_filtered_lrelu_params* p, void* stream);

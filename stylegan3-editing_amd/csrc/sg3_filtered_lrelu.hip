@@ -123,6 +123,12 @@ __device__ __forceinline__ v2f radial_fma(v2f a, v2f tq, v2f acc) {
     else      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "s"(tq), "v"(acc));
     return r;
 }
+// a + (b.y, b.x)
+__device__ __forceinline__ v2f add_swapped(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <bool FLIP>
 __device__ __forceinline__ v2f radial_mul(v2f a, v2f tq) {
     v2f r;
@@ -246,8 +252,9 @@ struct Stream {
     static __device__ __forceinline__ void step(State& st, const StreamParams& p, const T* __restrict__ plane, T* __restrict__ oplane,
                                                 unsigned char* __restrict__ splane, lds_f* sIn, lds_f* sOut, int i, int delta, int lane,
                                                 int oy0, int oy1, int ox0, int oxN, bool pairStore) {
-        constexpr bool RDOWN = RADIAL == 1 || RADIAL == 2;        // full 12x12 DOWN filter (config R forward)
-        constexpr bool UP2D = RADIAL >= 3;                         // full 12x12 UP filter (adjoint of those layers)
+        constexpr bool RDOWN = RADIAL == 1 || RADIAL == 2 || RADIAL >= 5;   // full 12x12 DOWN filter (config R forward)
+        constexpr bool FOLD = RADIAL >= 5;                         // ... whose rows read the same in both directions
+        constexpr bool UP2D = RADIAL == 3 || RADIAL == 4;          // full 12x12 UP filter (adjoint of those layers)
         // ---- input row -> LDS -> this lane's H-upsampled samples ----
         wave_lds_sync();                 // the previous row's sIn reads precede this row's writes
 #pragma unroll
@@ -389,7 +396,13 @@ struct Stream {
                 for (int q = 0; q < 4; q++) { const v4f t = srcr[q]; pr[2 * q] = (v2f){t.x, t.y}; pr[2 * q + 1] = (v2f){t.z, t.w}; }
                 wave_lds_sync();
                 const int headR = ((VPH + S * U + j) / D) % 6;
-                constexpr bool FLIPPED = RADIAL == 2;
+                constexpr bool FLIPPED = RADIAL == 2 || RADIAL == 6;
+                // mirror-symmetric rows: the samples j and 11 - j under an output column share a tap, so they are added
+                // first (three packed adds per column, the partner pair entering with its halves exchanged) and each of the
+                // six output rows then costs three packed FMAs per column instead of six
+                v2f fo[2][3];
+#pragma unroll
+                for (int q = 0; q < 3 && FOLD; q++) { fo[0][q] = add_swapped(pr[q], pr[5 - q]); fo[1][q] = add_swapped(pr[q + 1], pr[6 - q]); }
                 TapRow rowA, rowB;                                 // filter rows in flight: the next one loads under this one's FMAs
                 radial_row_issue(rowA, p.fd, FLIPPED ? kp : 11 - kp);
 #pragma unroll
@@ -401,7 +414,18 @@ struct Stream {
                     radial_row_wait(cur);
                     if (r < 5) radial_row_issue(nxt, p.fd, FLIPPED ? k + D : 11 - (k + D));
 #pragma unroll
-                    for (int q = 0; q < 6; q++) {
+                    for (int q = 0; q < 3 && FOLD; q++) {
+                        const v2f tq = radial_pair<true>(cur, q);       // memory order: taps (2q, 2q + 1) of the row
+                        if (k == 0 && q == 0) {
+                            st.acc[slot][0] = radial_mul<true>(fo[0][0], tq);
+                            st.acc[slot][1] = radial_mul<true>(fo[1][0], tq);
+                        } else {
+                            st.acc[slot][0] = radial_fma<true>(fo[0][q], tq, st.acc[slot][0]);
+                            st.acc[slot][1] = radial_fma<true>(fo[1][q], tq, st.acc[slot][1]);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 6 && !FOLD; q++) {
                         const v2f tq = radial_pair<FLIPPED>(cur, q);
                         if (k == 0 && q == 0) {
                             st.acc[slot][0] = radial_mul<FLIPPED>(pr[0], tq);
@@ -494,8 +518,11 @@ struct Stream {
 
     static __device__ __forceinline__ void run(const StreamParams& p) {
         static_assert((D == 2 || D == 4) && (6 * U) % D == 0, "streaming kernel: down is 2 or 4");
-        static_assert(RADIAL < 1 || RADIAL > 2 || (D == 2 && SIGNS != 2), "radial down filter: forward passes (plain or sign-writing), down 2");
-        static_assert(RADIAL < 3 || (U == 2 && SIGNS == 2), "2-D up filter: the adjoint pass, up 2");
+        constexpr bool RDOWN = RADIAL == 1 || RADIAL == 2 || RADIAL >= 5;
+        constexpr bool UP2D = RADIAL == 3 || RADIAL == 4;
+        static_assert(RADIAL >= 0 && RADIAL <= 6, "RADIAL: 0 separable, 1/2 12x12 down, 3/4 12x12 up, 5/6 12x12 down with mirror-symmetric rows");
+        static_assert(!RDOWN || (D == 2 && SIGNS != 2), "radial down filter: forward passes (plain or sign-writing), down 2");
+        static_assert(!UP2D || (U == 2 && SIGNS == 2), "2-D up filter: the adjoint pass, up 2");
         __shared__ __attribute__((aligned(16))) float lds[Cfg::SIN + Cfg::SOUT];
         lds_f* sIn = (lds_f*)lds;
         lds_f* sOut = (lds_f*)lds + Cfg::SIN;                               // row exchanged for the horizontal down pass
@@ -530,11 +557,11 @@ struct Stream {
         const float gU = (float)U;
 #pragma unroll
         for (int m = 0; m < Cfg::FU / 2; m++) {
-            if (RADIAL >= 3) { st.tuP[m] = splat(0.f); continue; }          // 2-D up filter: rows stream from the scalar cache
+            if (UP2D) { st.tuP[m] = splat(0.f); continue; }          // 2-D up filter: rows stream from the scalar cache
             const float f1 = p.fu[p.flip ? 2 * m + 1 : Cfg::FU - 2 - 2 * m], f0 = p.fu[p.flip ? 2 * m : Cfg::FU - 1 - 2 * m];
             st.tuP[m] = (v2f){to_sgpr(f1 * gU), to_sgpr(f0 * gU)};
         }
-        if (RADIAL == 1 || RADIAL == 2) {
+        if (RDOWN) {
 #pragma unroll
             for (int m = 0; m < Cfg::FD / 2; m++) st.tdP[m] = splat(0.f);      // unused: the 12x12 taps stream from the scalar cache
         } else {
@@ -716,6 +743,13 @@ static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
     dim3 g((unsigned)total), b(64);
 #define SG3_STREAM_LAUNCH(U, D, V, R, S) hipLaunchKernelGGL((flrelu_stream_kernel<T, U, D, V, R, S>), g, b, 0, st, p)
 #define SG3_STREAM_LAUNCH_V(U, R, S) do { if (vph == 0) SG3_STREAM_LAUNCH(U, 2, 0, R, S); else SG3_STREAM_LAUNCH(U, 2, 1, R, S); } while (0)
+    // separable | 12x12 | 12x12 flipped | 12x12 with mirror-symmetric rows | the same, flipped
+    const int variant = q.fdH == 0 ? 0 : (q.fdMirror ? (q.flip ? 6 : 5) : (q.flip ? 2 : 1));
+#define SG3_FORWARD_UP(U, S) do { switch (variant) { \
+        case 0: SG3_STREAM_LAUNCH_V(U, 0, S); break; case 1: SG3_STREAM_LAUNCH_V(U, 1, S); break; \
+        case 2: SG3_STREAM_LAUNCH_V(U, 2, S); break; case 5: SG3_STREAM_LAUNCH_V(U, 5, S); break; \
+        default: SG3_STREAM_LAUNCH_V(U, 6, S); break; } } while (0)
+#define SG3_FORWARD_LAUNCH(S) do { if (q.up == 2) SG3_FORWARD_UP(2, S); else SG3_FORWARD_UP(4, S); } while (0)
     if (q.readSigns) {
 #define SG3_ADJOINT_LAUNCH(R) do { \
         if (q.down == 2) SG3_STREAM_LAUNCH_V(2, R, 2); \
@@ -730,20 +764,12 @@ static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
         else SG3_ADJOINT_LAUNCH(3);
 #undef SG3_ADJOINT_LAUNCH
     } else if (q.writeSigns) {
-        const int variant = q.fdH == 0 ? 0 : (q.flip ? 2 : 1);
-        if (q.up == 2) {
-            if (variant == 0) SG3_STREAM_LAUNCH_V(2, 0, 1); else if (variant == 1) SG3_STREAM_LAUNCH_V(2, 1, 1); else SG3_STREAM_LAUNCH_V(2, 2, 1);
-        } else {
-            if (variant == 0) SG3_STREAM_LAUNCH_V(4, 0, 1); else if (variant == 1) SG3_STREAM_LAUNCH_V(4, 1, 1); else SG3_STREAM_LAUNCH_V(4, 2, 1);
-        }
+        SG3_FORWARD_LAUNCH(1);
     } else {
-        const int variant = q.fdH == 0 ? 0 : (q.flip ? 2 : 1);     // separable | radial | radial with flipped taps
-        if (q.up == 2) {
-            if (variant == 0) SG3_STREAM_LAUNCH_V(2, 0, 0); else if (variant == 1) SG3_STREAM_LAUNCH_V(2, 1, 0); else SG3_STREAM_LAUNCH_V(2, 2, 0);
-        } else {
-            if (variant == 0) SG3_STREAM_LAUNCH_V(4, 0, 0); else if (variant == 1) SG3_STREAM_LAUNCH_V(4, 1, 0); else SG3_STREAM_LAUNCH_V(4, 2, 0);
-        }
+        SG3_FORWARD_LAUNCH(0);
     }
+#undef SG3_FORWARD_LAUNCH
+#undef SG3_FORWARD_UP
 #undef SG3_STREAM_LAUNCH_V
 #undef SG3_STREAM_LAUNCH
     SG3_LAUNCH_CHECK("flrelu_stream_kernel");

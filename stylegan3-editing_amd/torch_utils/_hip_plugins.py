@@ -11,6 +11,7 @@ reference; the shared library itself never throws.  Output / sign tensors are al
 ABI terms) with the size formulas of the reference host code.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -22,6 +23,21 @@ INT_MAX = 2 ** 31 - 1
 def _require(cond, msg):
     if not cond:
         raise RuntimeError(msg)
+
+
+_mirror_cache = {}      # id(filter tensor) -> (weakref, version, bool)
+
+
+def _mirror_symmetric(f):
+    """f[r][c] == f[r][W-1-c] bit for bit?  One device comparison per filter tensor and version (the filters are module
+    buffers, so the same tensor comes back on every call); the entry dies with the tensor."""
+    key = id(f)
+    hit = _mirror_cache.get(key)
+    if hit is not None and hit[0]() is f and hit[1] == f._version:
+        return hit[2]
+    same = bool(torch.equal(f, f.flip(-1)))
+    _mirror_cache[key] = (weakref.ref(f, lambda _, k=key: _mirror_cache.pop(k, None)), f._version, same)
+    return same
 
 
 class FilteredLreluPlugin:
@@ -89,6 +105,7 @@ class FilteredLreluPlugin:
         p.sx, p.sy, p.swLimit = int(sx), int(sy), int(sw_limit)
         p.gain, p.slope, p.clamp = float(gain), float(slope), float(clamp)
         p.flip, p.writeSigns, p.readSigns = int(bool(flip_filters)), int(bool(writeSigns)), int(bool(readSigns))
+        p.fdMirror = int(fd.ndim == 2 and fd.shape[0] > 1 and _mirror_symmetric(fd))
         partial = None
         if return_sum:
             slots = int(lib.sg3_filtered_lrelu_sum_slots(N, C, yH.value, yW.value, int(down)))

@@ -97,14 +97,17 @@ def test_filtered_lrelu_radial_stream_kernel_sizes(shape, up, taps, pad):
     fs = 64
     fu = O.design_lowpass_filter(taps, 4.0, 8.0, fs * up / 2)
     fd = O.design_lowpass_filter(12, 5.0, 9.0, fs, radial=True)
-    fd = (fd + 0.01 * np.random.RandomState(8).rand(12, 12).astype(np.float32)).astype(np.float32)     # break the symmetry: exposes flips
+    noise = 0.01 * np.random.RandomState(8).rand(12, 12).astype(np.float32)
     x = rand(3, *shape); b = rand(4, shape[1])
-    for flip in (False, True):
-        c = dict(up=up, down=2, padding=pad, gain=float(np.sqrt(2)), slope=0.2, clamp=256, flip=flip)
-        y = _flrelu(c, T(x), T(b), T(fu), T(fd))
-        ref = O.filtered_lrelu(x, fu, fd, b, up, 2, pad, c['gain'], 0.2, 256, flip)
-        assert tuple(y.shape) == ref.shape
-        assert maxabs(y.cpu().numpy(), ref) <= 2e-5
+    # general taps (symmetry broken: exposes flips), then rows that read the same in both directions (what the radial design
+    # produces; the kernel then adds the two samples under a shared tap first) with the vertical symmetry still broken
+    for fd_case in ((fd + noise).astype(np.float32), (fd + noise + noise[:, ::-1]).astype(np.float32)):
+        for flip in (False, True):
+            c = dict(up=up, down=2, padding=pad, gain=float(np.sqrt(2)), slope=0.2, clamp=256, flip=flip)
+            y = _flrelu(c, T(x), T(b), T(fu), T(fd_case))
+            ref = O.filtered_lrelu(x, fu, fd_case, b, up, 2, pad, c['gain'], 0.2, 256, flip)
+            assert tuple(y.shape) == ref.shape
+            assert maxabs(y.cpu().numpy(), ref) <= 2e-5
 
 
 def test_filtered_lrelu_strided_input_and_bias():
@@ -194,7 +197,8 @@ def test_filtered_lrelu_fused_sign_kernels(shape, up, taps, pad, clamp):
     ((2, 2, 84, 84), 4, 24, [-2, -5, -2, -5], 256),             # config-R up-4 layer; adjoint: 12x12 up filter, down 4
     ((1, 1, 150, 276), 4, 24, [-2, -5, -2, -5], None),          # several strips / row chunks
 ])
-def test_filtered_lrelu_radial_training_kernels(shape, up, taps, pad, clamp):
+@pytest.mark.parametrize('mirror', [False, True])
+def test_filtered_lrelu_radial_training_kernels(shape, up, taps, pad, clamp, mirror):
     """Config-R training: the fused radial kernel writes the sign tensor and its adjoint (2-D 12x12 UP filter streamed from
     the scalar cache, sign read, separable down 2 / 4) runs fused too; output and gradients against autograd through the
     reference formulation on the CPU."""
@@ -204,7 +208,9 @@ def test_filtered_lrelu_radial_training_kernels(shape, up, taps, pad, clamp):
     fl._init()
     fu = O.design_lowpass_filter(taps, 4.0, 8.0, 64.0 * up / 2)
     fd = O.design_lowpass_filter(12, 5.0, 9.0, 64.0, radial=True)
-    fd = (fd + 0.01 * np.random.RandomState(8).rand(12, 12).astype(np.float32)).astype(np.float32)        # break the symmetry: exposes flips
+    noise = 0.01 * np.random.RandomState(8).rand(12, 12).astype(np.float32)
+    # break the symmetry (exposes flips); `mirror` keeps each row palindromic, which selects the folding forward kernel
+    fd = (fd + noise + (noise[:, ::-1] if mirror else 0)).astype(np.float32)
     xn, bn = rand(3, *shape), rand(4, shape[1])
     for flip in (False, True):
         kw = dict(up=up, down=2, padding=pad, gain=float(np.sqrt(2)), slope=0.2, clamp=clamp, flip_filter=flip)
