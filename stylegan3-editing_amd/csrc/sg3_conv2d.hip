@@ -355,6 +355,37 @@ conv2d_f16x3_kernel(PlainConvParams p, int* flag) {
 
     float* outp = p.out + (size_t)n * p.O * p.outH * p.outW;
     const int gx = x0 + li;
+    const unsigned planeB = (unsigned)(p.outH * p.outW) * 4u;
+    if ((unsigned long long)p.O * planeB < 0x7fffffffULL) {
+        // stores through a descriptor over this sample's output: the hardware range check drops channels beyond O and
+        // (offsets from 2^31) columns beyond the row; no per-store predicate or 64-bit address arithmetic
+        const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)outp, (short)0, (int)((unsigned)p.O * planeB), 0x00020000);
+#pragma unroll
+        for (int a = 0; a < TM; a++) {
+            const int oL = o0 + (wm * TM + a) * 32 + 4 * lh;
+            float bv[16], sl[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int o = min(oL + (r & 3) + 8 * (r >> 2), p.O - 1);                // channels beyond O are dropped by the store
+                bv[r] = p.bias ? p.bias[o] : 0.f;
+                sl[r] = p.act == 1 ? p.slope[o] : (p.act == 2 ? p.slope[0] : 1.f);
+            }
+            const unsigned laneBase = gx < p.outW ? (unsigned)oL * planeB + (unsigned)gx * 4u : 0x80000000u;
+#pragma unroll
+            for (int b = 0; b < TN; b++) {
+                const int gy = y0 + wn * TN + b;
+                if (gy >= p.outH) continue;                                              // wave-uniform
+                const unsigned rowOff = laneBase + (unsigned)(gy * p.outW) * 4u;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    float v = acc[a][b][r] + bv[r];
+                    if (p.act) v = v < 0.f ? v * sl[r] : v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orr, (int)(rowOff + (unsigned)((r & 3) + 8 * (r >> 2)) * planeB), 0, 0);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < TM; a++)
 #pragma unroll

@@ -391,6 +391,35 @@ modconv_f16x3_kernel(ConvParams p) {
 
     T* outp = (T*)p.out + (size_t)n * p.O * p.outH * p.outW;
     const int gx = x0 + li;
+    const unsigned planeB = (unsigned)(p.outH * p.outW) * (unsigned)sizeof(T);          // bytes per output channel plane
+    if ((unsigned long long)p.O * planeB < 0x7fffffffULL) {
+        // Stores through a descriptor over this sample's output: byte offset = channel * plane + row + column in 32 bits,
+        // and the hardware range check drops what lies outside -- channels beyond O (offset >= O planes) and, by
+        // starting at 2^31, the columns beyond the image.  No per-store predicate, no 64-bit address arithmetic: with
+        // two to eight K chunks per tile (the thin 1024^2 layers) the predicated form cost as much as a K chunk.
+        const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)outp, (short)0, (int)((unsigned)p.O * planeB), 0x00020000);
+        const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dcoef + (size_t)n * p.O), (short)0, p.O * 4, 0x00020000);
+        const int oL = o0 + wm * 32 + 4 * lh;                                            // this lane's first channel
+        const unsigned laneBase = gx < p.outW ? (unsigned)oL * planeB + (unsigned)gx * (unsigned)sizeof(T) : 0x80000000u;
+        float d[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            d[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, (oL + (r & 3) + 8 * (r >> 2)) * 4, 0, 0));
+#pragma unroll
+        for (int b = 0; b < TN; b++) {
+            const int gy = y0 + wn * TN + b;
+            if (gy >= p.outH) continue;                                                  // wave-uniform
+            const unsigned rowOff = laneBase + (unsigned)(gy * p.outW) * (unsigned)sizeof(T);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const unsigned off = rowOff + (unsigned)((r & 3) + 8 * (r >> 2)) * planeB;
+                const float v = acc[0][b][r] * d[r];
+                if (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orr, (int)off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), orr, (int)off, 0, 0);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < TM; a++)
 #pragma unroll
@@ -578,6 +607,34 @@ modconv1_f16x3_kernel(ConvParams p) {
     }
 
     T* outp = (T*)p.out + (size_t)n * p.O * P;
+    const unsigned planeB = (unsigned)P * (unsigned)sizeof(T);
+    if ((unsigned long long)p.O * planeB < 0x7fffffffULL) {
+        // descriptor stores, as in the 3x3 kernel: the range check drops channels beyond O and (offsets from 2^31) pixels
+        // beyond the plane
+        const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)outp, (short)0, (int)((unsigned)p.O * planeB), 0x00020000);
+        const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dcoef + (size_t)n * p.O), (short)0, p.O * 4, 0x00020000);
+#pragma unroll
+        for (int a = 0; a < TM; a++) {
+            const int oL = o0 + (wm * TM + a) * 32 + 4 * lh;
+            float d[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                d[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, (oL + (r & 3) + 8 * (r >> 2)) * 4, 0, 0));
+#pragma unroll
+            for (int b = 0; b < TN; b++) {
+                const int px = p0 + (wn * TN + b) * 32 + li;
+                const unsigned base = px < P ? (unsigned)oL * planeB + (unsigned)px * (unsigned)sizeof(T) : 0x80000000u;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const unsigned off = base + (unsigned)((r & 3) + 8 * (r >> 2)) * planeB;
+                    const float v = acc[a][b][r] * d[r];
+                    if (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orr, (int)off, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), orr, (int)off, 0, 0);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < TM; a++)
 #pragma unroll
