@@ -267,7 +267,11 @@ modconv_f16x3_kernel(ConvParams p) {
         bG[q] = ok ? (unsigned)(gy * p.W + gx) * (unsigned)sizeof(T) : 0x80000000u;
         bL[q] = e < NPIX ? e * 8 : -1;
     }
-    const float* sInN = p.sIn + (size_t)n * p.I;
+    // style scales of a chunk's 16 channels: lane c of every wave requests channel c together with the chunk's pixels (a
+    // descriptor over this sample's row of sIn: channels beyond I read 0, which also silences the padded channels) and
+    // stage() broadcasts them with v_readlane -- no scalar loads, waits or branches between the two barriers
+    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.sIn + (size_t)n * p.I), (short)0, p.I * 4, 0x00020000);
+    float rsc;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -281,6 +285,7 @@ modconv_f16x3_kernel(ConvParams p) {
     float rb[PX_PER][2][8];
 
     auto fetch = [&](int ch) {
+        rsc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, (ch * KC + (lane & 15)) * 4, 0, 0));
         const unsigned aoff = aG + (unsigned)ch * (AROW_V * 16);
 #pragma unroll
         for (int q = 0; q < A_PER; q++) {
@@ -306,10 +311,8 @@ modconv_f16x3_kernel(ConvParams p) {
 #pragma unroll
         for (int hf = 0; hf < 2; hf++)
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const int ci = ch * KC + hf * 8 + c;
-                sc[hf][c] = ci < p.I ? sInN[ci] : 0.f;                       // scalar loads; padded channels are multiplied by zero
-            }
+            for (int c = 0; c < 8; c++)
+                sc[hf][c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rsc), hf * 8 + c));
         if (aOk) {
 #pragma unroll
             for (int q = 0; q < A_PER; q++)
@@ -336,6 +339,16 @@ modconv_f16x3_kernel(ConvParams p) {
         }
     };
 
+    // demodulation coefficients of this lane's 16 output channels: requested first, consumed by the epilogue (channels
+    // beyond O read 0 through the range check)
+    const int oL = o0 + wm * 32 + 4 * lh;                                                // this lane's first channel
+    float d[16];
+    {
+        const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dcoef + (size_t)n * p.O), (short)0, p.O * 4, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            d[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, (oL + (r & 3) + 8 * (r >> 2)) * 4, 0, 0));
+    }
     fetch(0);
     for (int ch = 0; ch < p.nch; ch++) {
         __syncthreads();
@@ -398,13 +411,7 @@ modconv_f16x3_kernel(ConvParams p) {
         // starting at 2^31, the columns beyond the image.  No per-store predicate, no 64-bit address arithmetic: with
         // two to eight K chunks per tile (the thin 1024^2 layers) the predicated form cost as much as a K chunk.
         const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)outp, (short)0, (int)((unsigned)p.O * planeB), 0x00020000);
-        const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dcoef + (size_t)n * p.O), (short)0, p.O * 4, 0x00020000);
-        const int oL = o0 + wm * 32 + 4 * lh;                                            // this lane's first channel
         const unsigned laneBase = gx < p.outW ? (unsigned)oL * planeB + (unsigned)gx * (unsigned)sizeof(T) : 0x80000000u;
-        float d[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-            d[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, (oL + (r & 3) + 8 * (r >> 2)) * 4, 0, 0));
 #pragma unroll
         for (int b = 0; b < TN; b++) {
             const int gy = y0 + wn * TN + b;
@@ -497,7 +504,10 @@ modconv1_f16x3_kernel(ConvParams p) {
     // B: this thread's pixel pair (pairs beyond the plane read the next channel or zero: those columns are never stored)
     const int e2 = tid & 127;
     const unsigned bG = (p0 + 2 * e2 < P) ? (unsigned)(p0 + 2 * e2) * (unsigned)sizeof(T) : 0x80000000u;
-    const float* sInN = p.sIn + (size_t)n * p.I;
+    // style scales of this wave's 8 channels: requested by lanes 0..7 with the pixels, broadcast with v_readlane in stage()
+    // (channels beyond I read 0 through the range check, which also silences the padded channels)
+    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.sIn + (size_t)n * p.I), (short)0, p.I * 4, 0x00020000);
+    float rsc;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -511,6 +521,7 @@ modconv1_f16x3_kernel(ConvParams p) {
     typename bufld<T>::raw2 rb[8];                     // raw pixel pairs, one per channel (unpacked in stage)
 
     auto fetch = [&](int ch) {
+        rsc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, (ch * KC + ssub * 16 + kh * 8 + (tid & 7)) * 4, 0, 0));
 #pragma unroll
         for (int q = 0; q < A_PER; q++)
             ra[q] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)(aG[q] + (unsigned)ch * (AROW_V * 16)), 0, 0);
@@ -527,8 +538,7 @@ modconv1_f16x3_kernel(ConvParams p) {
         float rv[8][2];
 #pragma unroll
         for (int c = 0; c < 8; c++) {
-            const int ci = ch * KC + ssub * 16 + kh * 8 + c;
-            const float sc = ci < p.I ? sInN[ci] : 0.f;        // scalar load; padded channels are multiplied by zero
+            const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rsc), c));
             float v0, v1;
             bufld<T>::unpack2(rb[c], v0, v1);
             rv[c][0] = v0 * sc; rv[c][1] = v1 * sc;
