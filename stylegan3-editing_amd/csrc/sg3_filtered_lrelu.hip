@@ -109,6 +109,16 @@ __device__ __forceinline__ void radial_row_issue(TapRow& t, const float* fd, int
 __device__ __forceinline__ void radial_row_wait(TapRow& t) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t.a), "+s"(t.b), "+s"(t.c));
 }
+// first half of a filter row (taps 0..5), all a mirror-symmetric row needs
+struct TapHalf { v4f a; v2f b; };
+__device__ __forceinline__ void radial_half_issue(TapHalf& t, const float* fd, int row) {
+    const float* src = fd + row * 12;
+    asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x10" : "=&s"(t.a), "=&s"(t.b) : "s"(src));
+}
+__device__ __forceinline__ void radial_half_wait(TapHalf (&t)[6]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t[0].a), "+s"(t[0].b), "+s"(t[1].a), "+s"(t[1].b), "+s"(t[2].a), "+s"(t[2].b),
+                                          "+s"(t[3].a), "+s"(t[3].b), "+s"(t[4].a), "+s"(t[4].b), "+s"(t[5].a), "+s"(t[5].b));
+}
 // pair (g[k][2q], g[k][2q+1]) of the row (memory pair q with flip; memory pair 5-q, halves swapped, without)
 template <bool FLIP>
 __device__ __forceinline__ v2f radial_pair(const TapRow& t, int q) {
@@ -297,6 +307,14 @@ struct Stream {
         for (int j = 0; j < U; j++) {
             const int kv = U - 1 - j;                          // vertical up phase of this row
             v2f u0, u1;
+            // mirror-symmetric 12x12 down filter: the six half rows this upsampled row needs (36 taps) are requested now and
+            // arrive under the vertical up filter and the nonlinearity
+            TapHalf th[6];
+            if (FOLD) {
+                const int kp0 = (VPH + S * U + j) % D;
+#pragma unroll
+                for (int r = 0; r < 6; r++) radial_half_issue(th[r], p.fd, (RADIAL == 6) ? kp0 + r * D : 11 - (kp0 + r * D));
+            }
             if (UP2D) {
                 // 36 taps per upsampled sample: filter rows kv, kv + 2, .. against the six raw rows of the window; the rows
                 // stream through the scalar cache like the radial down filter's, the next one loading under this one's FMAs
@@ -403,19 +421,15 @@ struct Stream {
                 v2f fo[2][3];
 #pragma unroll
                 for (int q = 0; q < 3 && FOLD; q++) { fo[0][q] = add_swapped(pr[q], pr[5 - q]); fo[1][q] = add_swapped(pr[q + 1], pr[6 - q]); }
-                TapRow rowA, rowB;                                 // filter rows in flight: the next one loads under this one's FMAs
-                radial_row_issue(rowA, p.fd, FLIPPED ? kp : 11 - kp);
+                if (FOLD) radial_half_wait(th);
 #pragma unroll
-                for (int r = 0; r < 6; r++) {
+                for (int r = 0; r < 6 && FOLD; r++) {
                     const int slot = (headR + 5 - r) % 6;          // r = 5: oldest output row (completes first)
                     const int k = kp + r * D;                      // filter row of this upsampled row in that output row
-                    TapRow& cur = (r & 1) ? rowB : rowA;
-                    TapRow& nxt = (r & 1) ? rowA : rowB;
-                    radial_row_wait(cur);
-                    if (r < 5) radial_row_issue(nxt, p.fd, FLIPPED ? k + D : 11 - (k + D));
 #pragma unroll
-                    for (int q = 0; q < 3 && FOLD; q++) {
-                        const v2f tq = radial_pair<true>(cur, q);       // memory order: taps (2q, 2q + 1) of the row
+                    for (int q = 0; q < 3; q++) {
+                        // memory order: taps (2q, 2q + 1) of the row
+                        const v2f tq = q == 0 ? (v2f){th[r].a.x, th[r].a.y} : (q == 1 ? (v2f){th[r].a.z, th[r].a.w} : th[r].b);
                         if (k == 0 && q == 0) {
                             st.acc[slot][0] = radial_mul<true>(fo[0][0], tq);
                             st.acc[slot][1] = radial_mul<true>(fo[1][0], tq);
@@ -424,6 +438,17 @@ struct Stream {
                             st.acc[slot][1] = radial_fma<true>(fo[1][q], tq, st.acc[slot][1]);
                         }
                     }
+                }
+                TapRow rowA, rowB;                                 // filter rows in flight: the next one loads under this one's FMAs
+                if (!FOLD) radial_row_issue(rowA, p.fd, FLIPPED ? kp : 11 - kp);
+#pragma unroll
+                for (int r = 0; r < 6 && !FOLD; r++) {
+                    const int slot = (headR + 5 - r) % 6;          // r = 5: oldest output row (completes first)
+                    const int k = kp + r * D;                      // filter row of this upsampled row in that output row
+                    TapRow& cur = (r & 1) ? rowB : rowA;
+                    TapRow& nxt = (r & 1) ? rowA : rowB;
+                    radial_row_wait(cur);
+                    if (r < 5) radial_row_issue(nxt, p.fd, FLIPPED ? k + D : 11 - (k + D));
 #pragma unroll
                     for (int q = 0; q < 6 && !FOLD; q++) {
                         const v2f tq = radial_pair<FLIPPED>(cur, q);
