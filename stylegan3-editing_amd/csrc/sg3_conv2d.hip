@@ -356,7 +356,9 @@ conv2d_f16x3_kernel(PlainConvParams p, int* flag) {
     float* outp = p.out + (size_t)n * p.O * p.outH * p.outW;
     const int gx = x0 + li;
     const unsigned planeB = (unsigned)(p.outH * p.outW) * 4u;
-    if ((unsigned long long)p.O * planeB < 0x7fffffffULL) {
+    // every offset a lane can form -- channels of the padded last M tile included -- must stay below 2^31, so that nothing
+    // wraps around into the tensor: (padded O + one wave block) * plane < 2^31
+    if ((unsigned long long)(p.mTiles * BM + 32) * planeB < 0x7fffffffULL) {
         // stores through a descriptor over this sample's output: the hardware range check drops channels beyond O and
         // (offsets from 2^31) columns beyond the row; no per-store predicate or 64-bit address arithmetic
         const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)outp, (short)0, (int)((unsigned)p.O * planeB), 0x00020000);

@@ -405,7 +405,9 @@ modconv_f16x3_kernel(ConvParams p) {
     T* outp = (T*)p.out + (size_t)n * p.O * p.outH * p.outW;
     const int gx = x0 + li;
     const unsigned planeB = (unsigned)(p.outH * p.outW) * (unsigned)sizeof(T);          // bytes per output channel plane
-    if ((unsigned long long)p.O * planeB < 0x7fffffffULL) {
+    // every offset a lane can form -- channels of the padded last M tile included -- must stay below 2^31, so that nothing
+    // wraps around into the tensor: (padded O + one wave block) * plane < 2^31
+    if ((unsigned long long)(p.mTiles * BM + 32) * planeB < 0x7fffffffULL) {
         // Stores through a descriptor over this sample's output: byte offset = channel * plane + row + column in 32 bits,
         // and the hardware range check drops what lies outside -- channels beyond O (offset >= O planes) and, by
         // starting at 2^31, the columns beyond the image.  No per-store predicate, no 64-bit address arithmetic: with
@@ -618,7 +620,9 @@ modconv1_f16x3_kernel(ConvParams p) {
 
     T* outp = (T*)p.out + (size_t)n * p.O * P;
     const unsigned planeB = (unsigned)P * (unsigned)sizeof(T);
-    if ((unsigned long long)p.O * planeB < 0x7fffffffULL) {
+    // every offset a lane can form -- channels of the padded last M tile included -- must stay below 2^31, so that nothing
+    // wraps around into the tensor: (padded O + one wave block) * plane < 2^31
+    if ((unsigned long long)(p.mTiles * BM + 32) * planeB < 0x7fffffffULL) {
         // descriptor stores, as in the 3x3 kernel: the range check drops channels beyond O and (offsets from 2^31) pixels
         // beyond the plane
         const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)outp, (short)0, (int)((unsigned)p.O * planeB), 0x00020000);

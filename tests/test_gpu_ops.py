@@ -333,6 +333,31 @@ def test_modulated_conv2d_sizes(n, ci, co, h, k):
     assert maxabs(y2.cpu().numpy(), ref2) <= 3e-5 * max(1.0, float(np.abs(ref2).max()))
 
 
+@pytest.mark.parametrize('k', [3, 1])
+def test_modulated_conv2d_plane_beyond_descriptor_offsets(k):
+    """Output planes so large that (padded O + 32) * plane bytes passes 2^31: the kernels leave the descriptor-store
+    epilogue for 64-bit addresses.  Size-independent check: an interior window of the big result equals, bit for bit, the
+    convolution of the matching input crop (which takes the descriptor path)."""
+    from torch_utils.ops import modulated_conv as mc
+    ci, co = 16, (32 if k == 3 else 64)
+    side = 2960 if k == 3 else 2400                       # 64 * 2962^2 * 4 B = 2.25 GB;  (64 + 32) * 2400^2 * 4 B = 2.2 GB
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = (torch.rand([1, ci, side, side], device=DEV, generator=g) * 2 - 1) * 3
+    w = T(rand(81, co, ci, k, k)); s = T(rand(82, 1, ci) + 1)
+    kw = dict(demodulate=True, padding=k - 1, input_gain=torch.tensor(0.9, device=DEV), x_bound=4.0)
+    big = mc.modulated_conv2d(x, w, s, **kw)
+    assert tuple(big.shape) == (1, co, side + k - 1, side + k - 1)
+    for (y0, x0) in ((0, 0), (1500, 1777), (side - 300, side - 300)):
+        crop = x[:, :, y0:y0 + 300, x0:x0 + 300].contiguous()
+        small = mc.modulated_conv2d(crop, w, s, **kw)
+        m = k - 1                                          # rows / columns of `small` that see the crop's zero padding
+        a = big[:, :, y0 + 2 * m:y0 + 300 - m + m, x0 + 2 * m:x0 + 300 - m + m]
+        b = small[:, :, 2 * m:300, 2 * m:300]
+        assert a.shape == b.shape and torch.equal(a, b), (k, y0, x0)
+    del big, x
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize('n,ci,co,h', [(2, 323, 203, 22), (1, 128, 81, 40), (2, 51, 32, 70), (2, 512, 512, 12), (1, 203, 128, 37), (3, 81, 51, 50)])
 def test_modulated_conv2d_split_precision(n, ci, co, h):
     """fp16 hi/lo split on the fp16 matrix cores (x_bound given) is fp32-equivalent: compared with the fp64 result of
