@@ -30,6 +30,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0   # same guide: dense fp16 / bf16 MFMA peak (the headline figure with 2:1 sparsity is not used)
 
 
 def build_generator(cfg, device):
@@ -334,7 +335,8 @@ def main():
         total_bytes, _ = flrelu_algorithmic_bytes(G, args.batch)
         n_layers = len(G.synthesis.layer_names)
         fl_ms = timer.median_step_ms('filtered_lrelu', n_layers)         # per step, all 15 launches
-        conv_ms = timer.median_step_ms('modulated_conv2d', n_layers)
+        # 16 convolution launches per step: the channel mix of the Fourier-feature input runs on the 1x1 kernel too
+        conv_ms = timer.median_step_ms('modulated_conv2d', n_layers + 1)
         achieved = total_bytes / (fl_ms * 1e-3) / 1e9 if fl_ms > 0 else 0.0
         # HBM traffic of the same 15 launches from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes over this
         # command, summarised by tools/sum_traffic.py); only valid for the default workload
@@ -343,11 +345,13 @@ def main():
         if os.path.exists(tfile) and args.batch == 8 and args.config == 'T1024':
             with open(tfile) as f:
                 traffic = json.load(f)['traffic_bytes_per_step']
-        conv_flop = 0
+        inp = G.synthesis.input
+        conv_flop = 2 * inp.channels * inp.channels * int(inp.size[0]) * int(inp.size[1]) * args.batch
         for name in G.synthesis.layer_names:
             layer = getattr(G.synthesis, name)
             s = int(layer.in_size[0]) + layer.conv_kernel - 1
             conv_flop += 2 * layer.in_channels * layer.out_channels * layer.conv_kernel ** 2 * s * s * args.batch
+        conv_tflops = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         out = {
             'metric': 'FFHQ-1024 StyleGAN3-T synthesis imgs/sec', 'value': args.batch * world * args.steps / dt, 'unit': 'imgs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
@@ -358,8 +362,11 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': 'flrelu_stream_kernel (+pointwise ToRGB)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_step': total_bytes, 'kernel_ms_per_step': fl_ms},
-            'modconv': {'bound': 'mfma', 'tflops': conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
-                        'peak_fp32_mfma_tflops': 157.3, 'kernel_ms_per_step': conv_ms},
+            # second roofline, same shape: the modulated convolutions against the dense fp16 MFMA peak.  `achieved` counts the
+            # MFMA work issued (three fp16 products per fp32 product of the algorithm); `algorithmic` is the fp32 FLOP rate
+            'modconv': {'bound': 'mfma', 'kernel': 'modconv_f16x3_kernel (+input mix, ToRGB 1x1)', 'achieved': 3 * conv_tflops, 'peak': MFMA_F16_PEAK_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': 3 * conv_tflops / MFMA_F16_PEAK_TFLOPS, 'algorithmic': conv_tflops,
+                        'algorithmic_flop_per_step': conv_flop, 'kernel_ms_per_step': conv_ms},
         }
         out['inversion'] = inversion
         out['inversion_T1024'] = inversion_t
