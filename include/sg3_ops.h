@@ -275,6 +275,11 @@ typedef struct sg3_modconv_prep_params {
 
 SG3_API int sg3_modulated_conv2d_prep(const sg3_modconv_prep_params* p, void* stream);
 
+/* The same for `count` independent (w, s) pairs -- the layers of one Generator.synthesis call, whose styles are all known
+ * before the first convolution (networks_stylegan3.py:478-485 computes them layer by layer) -- in two launches instead of
+ * 2 * count.  No reference counterpart: the reference folds this arithmetic into torch ops inside modulated_conv2d (:39-56). */
+SG3_API int sg3_modulated_conv2d_prep_batch(const sg3_modconv_prep_params* list, int count, void* stream);
+
 typedef struct sg3_modconv_params {
     const void*    x;          /* [N,I,H,W] */
     const float*   wPacked;    /* from sg3_modulated_conv2d_prep */

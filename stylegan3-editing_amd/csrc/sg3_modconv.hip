@@ -737,10 +737,8 @@ static int launch_conv_1x1_small(const sg3_modconv_params& q, hipStream_t st) {
 
 // ---------------------------------------------------------------------------
 // prep A: one workgroup per output channel: normalise the filter, pack it, and emit wsq[o][i] = sum_taps wn^2
-__global__ void __launch_bounds__(256)
-modconv_prep_w_kernel(sg3_modconv_prep_params p, int kc, int nch) {
-    __shared__ float red[256];
-    const int o = blockIdx.x, taps = p.k * p.k, len = p.I * taps;
+static __device__ __forceinline__ void prep_w_body(const sg3_modconv_prep_params& p, int kc, int nch, int o, float* red) {
+    const int taps = p.k * p.k, len = p.I * taps;
     const float* w = p.w + (size_t)o * len;
     float scale = 1.f;
     if (p.demodulate) {
@@ -777,14 +775,36 @@ modconv_prep_w_kernel(sg3_modconv_prep_params p, int kc, int nch) {
         p.wsq[(size_t)o * p.I + i] = s;
     }
 }
+__global__ void __launch_bounds__(256)
+modconv_prep_w_kernel(sg3_modconv_prep_params p, int kc, int nch) {
+    __shared__ float red[256];
+    prep_w_body(p, kc, nch, blockIdx.x, red);
+}
+
+// The prep work of several layers in one launch each (sg3_modulated_conv2d_prep_batch): a single layer's prep kernels have a
+// few hundred small workgroups and are latency-bound (13 + 20 us); fifteen layers' worth run side by side in about the time of one.
+#define SG3_PREP_BATCH_MAX 16
+struct PrepBatch {
+    sg3_modconv_prep_params p[SG3_PREP_BATCH_MAX];
+    int first[SG3_PREP_BATCH_MAX + 1];     // first workgroup of each entry (prefix sums)
+    int kc[SG3_PREP_BATCH_MAX], nch[SG3_PREP_BATCH_MAX], gy[SG3_PREP_BATCH_MAX];
+    int count;
+};
+static __device__ __forceinline__ int batch_entry(const PrepBatch& b, int block) {
+    int l = 0;
+    while (l + 1 < b.count && block >= b.first[l + 1]) l++;
+    return l;
+}
+__global__ void __launch_bounds__(256)
+modconv_prep_w_batch_kernel(PrepBatch b) {
+    __shared__ float red[256];
+    const int l = batch_entry(b, (int)blockIdx.x);
+    prep_w_body(b.p[l], b.kc[l], b.nch[l], (int)blockIdx.x - b.first[l], red);
+}
 
 // prep B: gridDim.y workgroups per sample: normalise styles over the WHOLE batch, write sIn (first workgroup) and this
 // workgroup's share of dcoef (one output channel per wave at a time: coalesced rows of wsq, shuffle reduction)
-__global__ void __launch_bounds__(256)
-modconv_prep_s_kernel(sg3_modconv_prep_params p) {
-    __shared__ float red[256];
-    extern __shared__ float s2[];                         // [I] squared normalised styles | [I] scaled styles of this sample
-    const int n = blockIdx.x;
+static __device__ __forceinline__ void prep_s_body(const sg3_modconv_prep_params& p, int n, int by, int gy, float* red, float* s2) {
     float scale = 1.f;
     if (p.demodulate) {
         float s = 0.f;
@@ -819,11 +839,11 @@ modconv_prep_s_kernel(sg3_modconv_prep_params p) {
         down = ldexpf(1.f, -e); up = ldexpf(1.f, e);
     }
     __syncthreads();
-    if (blockIdx.y == 0)
+    if (by == 0)
         for (int i = threadIdx.x; i < p.I; i += 256) p.sIn[(size_t)n * p.I + i] = s2[p.I + i] * down;
     if (p.demodulate) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        for (int o = blockIdx.y * 4 + wave; o < p.O; o += gridDim.y * 4) {
+        for (int o = by * 4 + wave; o < p.O; o += gy * 4) {
             const float* wq = p.wsq + (size_t)o * p.I;
             float s = 0.f;
             for (int i = lane; i < p.I; i += 64) s += wq[i] * s2[i];
@@ -832,8 +852,22 @@ modconv_prep_s_kernel(sg3_modconv_prep_params p) {
             if (lane == 0) p.dcoef[(size_t)n * p.O + o] = rsqrtf(s + 1e-8f) * up;
         }
     } else if (p.precision != SG3_CONV_FP32) {
-        for (int o = blockIdx.y * 256 + threadIdx.x; o < p.O; o += gridDim.y * 256) p.dcoef[(size_t)n * p.O + o] = up;
+        for (int o = by * 256 + threadIdx.x; o < p.O; o += gy * 256) p.dcoef[(size_t)n * p.O + o] = up;
     }
+}
+__global__ void __launch_bounds__(256)
+modconv_prep_s_kernel(sg3_modconv_prep_params p) {
+    __shared__ float red[256];
+    extern __shared__ float s2[];                         // [I] squared normalised styles | [I] scaled styles of this sample
+    prep_s_body(p, blockIdx.x, blockIdx.y, gridDim.y, red, s2);
+}
+__global__ void __launch_bounds__(256)
+modconv_prep_s_batch_kernel(PrepBatch b) {
+    __shared__ float red[256];
+    extern __shared__ float s2[];
+    const int l = batch_entry(b, (int)blockIdx.x);
+    const int local = (int)blockIdx.x - b.first[l], gy = b.gy[l];
+    prep_s_body(b.p[l], local / gy, local % gy, gy, red, s2);
 }
 
 template <typename T, int KS, int WM, int WN, int TM, int TN>
@@ -950,7 +984,7 @@ int64_t sg3_modconv_packed_floats(int O, int I, int k, int precision) {
     return (int64_t)O * sg3::ceil_div(I, kc) * (k * k) * kc;
 }
 
-int sg3_modulated_conv2d_prep(const sg3_modconv_prep_params* p, void* stream) {
+static int prep_validate(const sg3_modconv_prep_params* p) {
     using namespace sg3;
     SG3_REQUIRE(p && p->w && p->s && p->wPacked && p->wsq && p->sIn, "modulated_conv2d_prep: null tensor");
     SG3_REQUIRE(p->N > 0 && p->I > 0 && p->O > 0, "modulated_conv2d_prep: empty tensor");
@@ -963,6 +997,43 @@ int sg3_modulated_conv2d_prep(const sg3_modconv_prep_params* p, void* stream) {
     if (p->precision != SG3_CONV_FP32) {
         SG3_REQUIRE((p->xBound > 0.f || p->xBoundDev) && p->dcoef, "modulated_conv2d_prep: f16x3 needs xBound > 0 and a dcoef buffer");
     }
+    return SG3_OK;
+}
+
+int sg3_modulated_conv2d_prep_batch(const sg3_modconv_prep_params* list, int count, void* stream) {
+    using namespace sg3;
+    SG3_REQUIRE(list && count > 0, "modulated_conv2d_prep_batch: empty list");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < count; base += SG3_PREP_BATCH_MAX) {
+        PrepBatch bw, bs;
+        const int m = std::min(SG3_PREP_BATCH_MAX, count - base);
+        size_t lds = 0;
+        bw.count = bs.count = m;
+        bw.first[0] = bs.first[0] = 0;
+        for (int j = 0; j < m; j++) {
+            const sg3_modconv_prep_params* p = list + base + j;
+            const int rc = prep_validate(p);
+            if (rc != SG3_OK) return rc;
+            const int kc = packed_kc(p->k);
+            const int nch = p->precision != SG3_CONV_FP32 ? f16x3_chunks(p->I, p->k) : ceil_div(p->I, kc);
+            const int gy = std::min(16, ceil_div(p->O, 32));
+            bw.p[j] = bs.p[j] = *p;
+            bw.kc[j] = bs.kc[j] = kc; bw.nch[j] = bs.nch[j] = nch; bw.gy[j] = bs.gy[j] = gy;
+            bw.first[j + 1] = bw.first[j] + p->O;
+            bs.first[j + 1] = bs.first[j] + p->N * gy;
+            lds = std::max(lds, (size_t)p->I * 2 * sizeof(float));
+        }
+        hipLaunchKernelGGL(modconv_prep_w_batch_kernel, dim3(bw.first[m]), dim3(256), 0, st, bw);
+        SG3_LAUNCH_CHECK("modconv_prep_w_batch_kernel");
+        hipLaunchKernelGGL(modconv_prep_s_batch_kernel, dim3(bs.first[m]), dim3(256), lds, st, bs);
+        SG3_LAUNCH_CHECK("modconv_prep_s_batch_kernel");
+    }
+    return SG3_OK;
+}
+
+int sg3_modulated_conv2d_prep(const sg3_modconv_prep_params* p, void* stream) {
+    using namespace sg3;
+    { const int rc = prep_validate(p); if (rc != SG3_OK) return rc; }
     hipStream_t st = (hipStream_t)stream;
     const int kc = packed_kc(p->k);
     const int nch = p->precision != SG3_CONV_FP32 ? f16x3_chunks(p->I, p->k) : ceil_div(p->I, kc);

@@ -51,13 +51,14 @@ def _summary(module, *rows):
 
 
 @misc.profiled_function
-def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, x_bound=None):
+def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, x_bound=None, prepared=None):
     """x [N,I,H,W], w [O,I,kh,kw], s [N,I], input_gain [] | [I] | [N,I]  ->  [N,O,H',W'].
 
     Equals a per-sample convolution with weights  w * s[n] (unit-normalised and demodulated when `demodulate`) times
     `input_gain` (reference :24-63).  `x_bound` is an extension: a guaranteed bound on |x| that lets the HIP kernel use
     its split-precision matrix-core path (torch_utils/ops/modulated_conv.py)."""
-    return _modconv.modulated_conv2d(x, w, s, demodulate=demodulate, padding=padding, input_gain=input_gain, x_bound=x_bound)
+    return _modconv.modulated_conv2d(x, w, s, demodulate=demodulate, padding=padding, input_gain=input_gain, x_bound=x_bound,
+                                     prepared=prepared)
 
 
 
@@ -286,7 +287,16 @@ class SynthesisLayer(torch.nn.Module):
             styles = styles * (1 / np.sqrt(self.in_channels * (self.conv_kernel ** 2)))
         return styles
 
-    def forward(self, x, w, styles=None, noise_mode='random', force_fp32=False, update_emas=False):
+    def compute_dtype(self, force_fp32, device_type):
+        return torch.float16 if (self.use_fp16 and not force_fp32 and device_type == 'cuda') else torch.float32
+
+    def conv_spec(self, styles, n, force_fp32):
+        """This layer's entry for `modulated_conv.prepare_batch`: everything its convolution's prep work depends on."""
+        return dict(w=self.weight, s=styles, demodulate=not self.is_torgb, padding=self.conv_kernel - 1,
+                    input_gain=self.magnitude_ema.rsqrt(), x_bound=getattr(self, 'input_bound', None), n=n,
+                    h=int(self.in_size[1]), wd=int(self.in_size[0]), dtype=self.compute_dtype(force_fp32, 'cuda'))
+
+    def forward(self, x, w, styles=None, noise_mode='random', force_fp32=False, update_emas=False, prepared=None):
         assert noise_mode in ['random', 'const', 'none']  # kept for API compatibility; SG3 has no noise inputs
         in_w, in_h = (int(v) for v in self.in_size)
         out_w, out_h = (int(v) for v in self.out_size)
@@ -299,10 +309,10 @@ class SynthesisLayer(torch.nn.Module):
             misc.assert_shape(w, [x.shape[0], self.w_dim])
             styles = self.styles_from_w(w)
 
-        half = self.use_fp16 and not force_fp32 and x.device.type == 'cuda'
-        dtype = torch.float16 if half else torch.float32
+        dtype = self.compute_dtype(force_fp32, x.device.type)
         x = modulated_conv2d(x=x.to(dtype), w=self.weight, s=styles, padding=self.conv_kernel - 1,
-                             demodulate=(not self.is_torgb), input_gain=input_gain, x_bound=getattr(self, 'input_bound', None))
+                             demodulate=(not self.is_torgb), input_gain=input_gain, x_bound=getattr(self, 'input_bound', None),
+                             prepared=prepared)
         x = filtered_lrelu.filtered_lrelu(
             x=x, fu=self.up_filter, fd=self.down_filter, b=self.bias.to(x.dtype), up=self.up_factor, down=self.down_factor,
             padding=self.padding, gain=(1 if self.is_torgb else np.sqrt(2)), slope=(1 if self.is_torgb else 0.2), clamp=self.conv_clamp)
@@ -380,6 +390,8 @@ class SynthesisNetwork(torch.nn.Module):
             setattr(self, name, layer)
             self.layer_names.append(name)
 
+    batch_prep = True          # class-level switch (tests compare against per-layer preparation)
+
     def layers(self):
         return [getattr(self, n) for n in self.layer_names]
 
@@ -395,16 +407,31 @@ class SynthesisNetwork(torch.nn.Module):
         """ws [N, num_ws, w_dim]  ->  image [N, img_channels, R, R] (fp32).
         With `all_s` (dict from W2S, possibly edited) the affine layers are bypassed: StyleSpace path."""
         self._propagate_bounds()
+        layers = self.layers()
         if all_s is None:
             misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
             per_layer = ws.to(torch.float32).unbind(dim=1)
-            x = self.input(per_layer[0])
-            for layer, w in zip(self.layers(), per_layer[1:]):
-                x = layer(x, w, **layer_kwargs)
+            t_in = self.input.transform_params(per_layer[0])
+            styles = None
         else:
-            x = self.input(None, t=all_s['input'])
-            for name, layer in zip(self.layer_names, self.layers()):
-                x = layer(x, None, styles=all_s[name], **layer_kwargs)
+            t_in = all_s['input']
+            styles = [all_s[name] for name in self.layer_names]
+        # Inference on the GPU: every layer's styles are known before the first convolution, so the weight / style preparation
+        # of all convolutions is issued as one batch (two launches instead of thirty small, latency-bound ones)
+        batched = (self.batch_prep and t_in.is_cuda and not torch.is_grad_enabled() and not layer_kwargs.get('update_emas', False)
+                   and all(k in ('noise_mode', 'force_fp32', 'update_emas') for k in layer_kwargs))
+        prepared = [None] * len(layers)
+        if batched:
+            if styles is None:
+                styles = [layer.styles_from_w(w) for layer, w in zip(layers, per_layer[1:])]
+            force_fp32 = bool(layer_kwargs.get('force_fp32', False))
+            prepared = _modconv.prepare_batch([layer.conv_spec(s, int(t_in.shape[0]), force_fp32) for layer, s in zip(layers, styles)])
+        x = self.input(None, t=t_in)
+        for j, layer in enumerate(layers):
+            if styles is not None:
+                x = layer(x, None, styles=styles[j], prepared=prepared[j], **layer_kwargs)
+            else:
+                x = layer(x, per_layer[j + 1], **layer_kwargs)
         if self.output_scale != 1:
             x = x * self.output_scale
         misc.assert_shape(x, [None, self.img_channels, self.img_resolution, self.img_resolution])

@@ -90,6 +90,7 @@ EXPORTS = [
     ('sg3_modconv_packed_floats', ctypes.c_int64, [ctypes.c_int] * 4),
     ('sg3_modulated_conv2d', ctypes.c_int, [ctypes.POINTER(ModconvParams), c_vp]),
     ('sg3_modulated_conv2d_prep', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), c_vp]),
+    ('sg3_modulated_conv2d_prep_batch', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), ctypes.c_int, c_vp]),
     ('sg3_conv2d', ctypes.c_int, [ctypes.POINTER(Conv2dParams), c_vp]),
     ('sg3_conv2d_wgrad_splits', ctypes.c_int, [ctypes.c_int] * 7 + [ctypes.POINTER(ctypes.c_int)] * 2),
     ('sg3_conv2d_wgrad', ctypes.c_int, [ctypes.POINTER(WgradParams), c_vp]),

@@ -63,19 +63,20 @@ def _effective_weights(w, s, demodulate, input_gain, n):
     return w
 
 
-def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None, x_bound_dev=None, out_scale=None):
-    """prep + implicit-GEMM kernels.  Returns (out, sIn [N,I], dcoef [N,O] or None): the two per-sample scale vectors are
-    what the data-gradient pass needs.  `x_bound_dev`: one-element device tensor holding the bound; `out_scale` [N,O]: extra
-    per-sample output-channel scale folded into the epilogue coefficient."""
-    n, ci, h, wd = (int(v) for v in x.shape)
-    co, ci2, k, k2 = (int(v) for v in w.shape)
-    if k != k2 or ci != ci2 or k not in (1, 3):
+class _Prepared:
+    """What the prep kernels produce for one (w, s) pair -- packed normalised weights, per-sample input scales and
+    demodulation coefficients -- plus the settings the convolution launch must repeat."""
+    __slots__ = ('wn', 'wsq', 's_in', 'dcoef', 'prec', 'key', 'params', 'keep')
+
+
+def _plan(w, s, demodulate, padding, input_gain, x_bound, x_bound_dev, n, h, wd, dtype, dev):
+    """Choose the arithmetic, allocate the prep outputs and fill the prep parameter block (nothing is launched)."""
+    co, ci, k, k2 = (int(v) for v in w.shape)
+    if k != k2 or k not in (1, 3):
         raise RuntimeError(f'modulated_conv2d: unsupported weight shape {tuple(w.shape)}')
-    if x.dtype not in (torch.float32, torch.float16):
-        raise RuntimeError(f'modulated_conv2d: unsupported dtype {x.dtype}')
+    if dtype not in (torch.float32, torch.float16):
+        raise RuntimeError(f'modulated_conv2d: unsupported dtype {dtype}')
     lib = abi.load()
-    dev = x.device
-    x = x.contiguous()
     w32 = w.detach().to(torch.float32).contiguous()
     s32 = s.detach().to(torch.float32).contiguous()
     gmode, gptr = 0, None
@@ -89,38 +90,79 @@ def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None, x_bound_dev=
         else:
             gmode, g = 3, g.expand(n, ci).contiguous()
         gptr = g
-    if x.dtype == torch.float16 and x_bound is None and x_bound_dev is None:
+    if dtype == torch.float16 and x_bound is None and x_bound_dev is None:
         x_bound = 65504.0                                   # the dtype's own range
     bounded = x_bound_dev is not None or (x_bound is not None and x_bound > 0)
     # 1x1: ToRGB (O <= 4) is HBM-bound and has its own kernel; the GEMM kernel loads pixel pairs (even plane size)
     split = precision == 'f16x3' and (k == 3 or (padding == 0 and co > 4 and (h * wd) % 2 == 0)) and bounded
-    prec = (abi.SG3_CONV_F16 if x.dtype == torch.float16 else abi.SG3_CONV_F16X3) if split else abi.SG3_CONV_FP32
-    wn = torch.empty([int(lib.sg3_modconv_packed_floats(co, ci, k, prec))], dtype=torch.float32, device=dev)
-    wsq = torch.empty([co, ci], dtype=torch.float32, device=dev)
-    s_in = torch.empty([n, ci], dtype=torch.float32, device=dev)
-    dcoef = torch.empty([n, co], dtype=torch.float32, device=dev) if (demodulate or split) else None
-    oh, ow = h + 2 * padding - k + 1, wd + 2 * padding - k + 1
-    out = torch.empty([n, co, oh, ow], dtype=x.dtype, device=dev)
+    prec = (abi.SG3_CONV_F16 if dtype == torch.float16 else abi.SG3_CONV_F16X3) if split else abi.SG3_CONV_FP32
+    pr = _Prepared()
+    pr.prec = prec
+    pr.key = (n, ci, co, k, h, wd, int(padding), dtype)
+    pr.wn = torch.empty([int(lib.sg3_modconv_packed_floats(co, ci, k, prec))], dtype=torch.float32, device=dev)
+    pr.wsq = torch.empty([co, ci], dtype=torch.float32, device=dev)
+    pr.s_in = torch.empty([n, ci], dtype=torch.float32, device=dev)
+    pr.dcoef = torch.empty([n, co], dtype=torch.float32, device=dev) if (demodulate or split) else None
+    pr.keep = (w32, s32, gptr, x_bound_dev)                 # inputs of the prep launch stay alive with its outputs
+    pp = abi.ModconvPrepParams()
+    pp.w, pp.s, pp.wPacked, pp.wsq, pp.sIn, pp.dcoef = abi.ptr(w32), abi.ptr(s32), abi.ptr(pr.wn), abi.ptr(pr.wsq), abi.ptr(pr.s_in), abi.ptr(pr.dcoef)
+    pp.inputGain, pp.inputGainMode = abi.ptr(gptr), gmode
+    pp.N, pp.I, pp.O, pp.k, pp.demodulate = n, ci, co, k, int(bool(demodulate))
+    pp.precision = prec
+    pp.xBound = float(x_bound) if (split and x_bound_dev is None) else 0.0
+    pp.xBoundDev = abi.ptr(x_bound_dev) if (split and x_bound_dev is not None) else None
+    pr.params = pp
+    return pr
+
+
+def prepare_batch(specs):
+    """Prep work of several modulated convolutions in two launches (sg3_modulated_conv2d_prep_batch).  `specs`: dicts with
+    w, s, demodulate, padding, input_gain, x_bound, n, h, wd, dtype -- the layers of one synthesis pass, whose styles are
+    all known before the first convolution.  Returns one `_Prepared` per spec, to be handed to `modulated_conv2d(prepared=)`."""
+    if not specs:
+        return []
+    lib = abi.load()
+    dev = specs[0]['w'].device
+    plans = [_plan(sp['w'], sp['s'], sp['demodulate'], sp['padding'], sp.get('input_gain'), sp.get('x_bound'), None,
+                   int(sp['n']), int(sp['h']), int(sp['wd']), sp['dtype'], dev) for sp in specs]
+    block = (abi.ModconvPrepParams * len(plans))(*[pl.params for pl in plans])
+    with torch.cuda.device(dev):
+        abi.check(lib.sg3_modulated_conv2d_prep_batch(block, len(plans), abi.stream_ptr(dev)), 'sg3_modulated_conv2d_prep_batch')
+    return plans
+
+
+def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None, x_bound_dev=None, out_scale=None, prepared=None):
+    """prep + implicit-GEMM kernels.  Returns (out, sIn [N,I], dcoef [N,O] or None): the two per-sample scale vectors are
+    what the data-gradient pass needs.  `x_bound_dev`: one-element device tensor holding the bound; `out_scale` [N,O]: extra
+    per-sample output-channel scale folded into the epilogue coefficient; `prepared`: the outcome of `prepare_batch` for
+    exactly this call (then no prep kernel is launched here)."""
+    n, ci, h, wd = (int(v) for v in x.shape)
+    co, ci2, k, _ = (int(v) for v in w.shape)
+    if ci != ci2:
+        raise RuntimeError(f'modulated_conv2d: x has {ci} channels, w expects {ci2}')
+    lib = abi.load()
+    dev = x.device
+    x = x.contiguous()
+    pr = prepared
+    if pr is not None and pr.key != (n, ci, co, k, h, wd, int(padding), x.dtype):
+        raise RuntimeError(f'modulated_conv2d: prepared for {pr.key}, called with {(n, ci, co, k, h, wd, int(padding), x.dtype)}')
     stream = abi.stream_ptr(dev)
     with torch.cuda.device(dev):
-        pp = abi.ModconvPrepParams()
-        pp.w, pp.s, pp.wPacked, pp.wsq, pp.sIn, pp.dcoef = abi.ptr(w32), abi.ptr(s32), abi.ptr(wn), abi.ptr(wsq), abi.ptr(s_in), abi.ptr(dcoef)
-        pp.inputGain, pp.inputGainMode = abi.ptr(gptr), gmode
-        pp.N, pp.I, pp.O, pp.k, pp.demodulate = n, ci, co, k, int(bool(demodulate))
-        pp.precision = prec
-        pp.xBound = float(x_bound) if (split and x_bound_dev is None) else 0.0
-        pp.xBoundDev = abi.ptr(x_bound_dev) if (split and x_bound_dev is not None) else None
-        abi.check(lib.sg3_modulated_conv2d_prep(ctypes.byref(pp), stream), 'sg3_modulated_conv2d_prep')
-        coef = dcoef
+        if pr is None:
+            pr = _plan(w, s, demodulate, padding, input_gain, x_bound, x_bound_dev, n, h, wd, x.dtype, dev)
+            abi.check(lib.sg3_modulated_conv2d_prep(ctypes.byref(pr.params), stream), 'sg3_modulated_conv2d_prep')
+        oh, ow = h + 2 * padding - k + 1, wd + 2 * padding - k + 1
+        out = torch.empty([n, co, oh, ow], dtype=x.dtype, device=dev)
+        coef = pr.dcoef
         if out_scale is not None:
-            coef = out_scale.to(torch.float32).contiguous() if dcoef is None else dcoef * out_scale
+            coef = out_scale.to(torch.float32).contiguous() if pr.dcoef is None else pr.dcoef * out_scale
         cp = abi.ModconvParams()
-        cp.x, cp.wPacked, cp.sIn, cp.dcoef, cp.out = abi.ptr(x), abi.ptr(wn), abi.ptr(s_in), abi.ptr(coef), abi.ptr(out)
+        cp.x, cp.wPacked, cp.sIn, cp.dcoef, cp.out = abi.ptr(x), abi.ptr(pr.wn), abi.ptr(pr.s_in), abi.ptr(coef), abi.ptr(out)
         cp.dtype = abi.dtype_code(x.dtype)
         cp.N, cp.I, cp.O, cp.H, cp.W, cp.k, cp.pad = n, ci, co, h, wd, k, int(padding)
-        cp.precision = prec
+        cp.precision = pr.prec
         abi.check(lib.sg3_modulated_conv2d(ctypes.byref(cp), stream), 'sg3_modulated_conv2d')
-    return out, s_in, dcoef
+    return out, pr.s_in, pr.dcoef
 
 
 def _data_gradient(dy, w, s_in, dcoef, demodulate, padding, dy_amax=None):
@@ -173,8 +215,8 @@ def _weight_gradient(x, dy, k, padding, x_amax=None, dy_amax=None):
 
 class _ModulatedConv2dHip(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, s, input_gain, demodulate, padding, x_bound):  # pylint: disable=arguments-differ
-        out, s_in, dcoef = _launch(x, w, s, demodulate, padding, input_gain, x_bound)
+    def forward(ctx, x, w, s, input_gain, demodulate, padding, x_bound, prepared=None):  # pylint: disable=arguments-differ
+        out, s_in, dcoef = _launch(x, w, s, demodulate, padding, input_gain, x_bound, prepared=prepared)
         ctx.save_for_backward(x, w, s, input_gain if input_gain is not None else torch.empty(0), s_in,
                               dcoef if dcoef is not None else torch.empty(0))
         ctx.cfg = (demodulate, padding, input_gain is not None)
@@ -186,7 +228,7 @@ class _ModulatedConv2dHip(torch.autograd.Function):
         x, w, s, g, s_in, dcoef = ctx.saved_tensors
         demodulate, padding, has_gain = ctx.cfg
         need = ctx.needs_input_grad
-        out = [None] * 7
+        out = [None] * 8
         if torch.is_grad_enabled():
             # higher-order gradients: differentiate the reference formulation itself
             ins, idx = [], []
@@ -229,9 +271,10 @@ class _ModulatedConv2dHip(torch.autograd.Function):
 
 
 @misc.profiled_function
-def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, impl='cuda', x_bound=None):
+def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, impl='cuda', x_bound=None, prepared=None):
     """x [N,I,H,W], w [O,I,k,k], s [N,I]; input_gain [], [I] or [N,I].  Returns [N,O,H+2p-k+1,W+2p-k+1] in x.dtype.
-    `x_bound` (optional float): a guaranteed upper bound on |x|; enables the split-precision MFMA path (see `precision`)."""
+    `x_bound` (optional float): a guaranteed upper bound on |x|; enables the split-precision MFMA path (see `precision`).
+    `prepared` (optional): this call's entry of `prepare_batch`, made from the same w, s, input_gain and x_bound."""
     assert impl in ['ref', 'cuda']
     with misc.suppress_tracer_warnings():
         n = int(x.shape[0])
@@ -240,5 +283,5 @@ def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, impl=
     misc.assert_shape(x, [n, i, None, None])
     misc.assert_shape(s, [n, i])
     if impl == 'cuda' and x.device.type == 'cuda':
-        return _ModulatedConv2dHip.apply(x, w, s, input_gain, bool(demodulate), int(padding), x_bound)
+        return _ModulatedConv2dHip.apply(x, w, s, input_gain, bool(demodulate), int(padding), x_bound, prepared)
     return _composite(x, w, s, demodulate, padding, input_gain)

@@ -154,3 +154,33 @@ def test_config_r_full_size_against_reference_samples(cfg):
     assert maxabs(img[:1, :, ::16, ::16].cpu().numpy(), g[f'{cfg}/img_sub']) <= 1e-4
     assert maxabs(img[:1, :, [0, res // 2 - 1, res - 1], :].cpu().numpy(), g[f'{cfg}/img_rows']) <= 1e-4
     assert abs(img[:1].mean().item() - g[f'{cfg}/img_stats'][0]) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_batched_prep_matches_per_layer_prep():
+    """Inference batches the weight / style preparation of all convolutions into two launches (prepare_batch); with
+    the switch off every layer prepares for itself.  Same kernels, same numbers: the images are identical bit for bit.
+    A prepared entry used for another call shape is refused."""
+    import torch
+    from synth_weights import synth_ws
+    from torch_utils.ops import modulated_conv as mc
+    G = build_product_generator('Ttiny', device='cuda:0')
+    ws = torch.from_numpy(synth_ws(2, G.num_ws, G.w_dim, 3)).cuda()
+    with torch.no_grad():
+        a = G.synthesis(ws, noise_mode='const', force_fp32=True)
+        a16 = G.synthesis(ws, noise_mode='const')
+        s = G.synthesis.W2S(ws)
+        a_s = G.synthesis(None, all_s=s, noise_mode='const', force_fp32=True)
+        G.synthesis.batch_prep = False
+        try:
+            b = G.synthesis(ws, noise_mode='const', force_fp32=True)
+            b16 = G.synthesis(ws, noise_mode='const')
+        finally:
+            del G.synthesis.batch_prep
+    assert torch.equal(a, b) and torch.equal(a16, b16) and torch.equal(a, a_s)
+    layer = G.synthesis.layers()[0]
+    spec = layer.conv_spec(s[G.synthesis.layer_names[0]], 2, True)
+    pr = mc.prepare_batch([spec])[0]
+    x = torch.randn(2, layer.in_channels, int(layer.in_size[1]) + 2, int(layer.in_size[0]), device='cuda:0')
+    with pytest.raises(RuntimeError, match='prepared for'):
+        mc.modulated_conv2d(x, layer.weight, spec['s'], padding=spec['padding'], input_gain=spec['input_gain'], x_bound=1e3, prepared=pr)
