@@ -28,6 +28,9 @@ for _p in (os.path.join(ROOT, 'stylegan3-editing_amd'), os.path.join(ROOT, 'test
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
+from torch_utils import custom_ops  # noqa: E402
+
+custom_ops.verbosity = 'none'     # stdout carries exactly one line: the JSON result
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F16_PEAK_TFLOPS = 2500.0   # same guide: dense fp16 / bf16 MFMA peak (the headline figure with 2:1 sparsity is not used)
