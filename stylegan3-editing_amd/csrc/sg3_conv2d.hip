@@ -255,8 +255,20 @@ conv2d_f16x3_kernel(PlainConvParams p, int* flag) {
     u32x4 ra[A_PER];
     float rb[PX_PER][2][8];
     float peak = 0.f;
+    // per-channel affine in front of the convolution (the folded BatchNorm): lane c of every wave requests scale / shift of
+    // channel c of the chunk together with the pixels (range-checked: channels beyond I read 0 and silence the padded
+    // channels); stage() broadcasts them with v_readlane.  Nothing in fetch() touches the loaded values, so their
+    // s_waitcnt sits behind the MFMA loop of the previous chunk, not in front of it.
+    const bool hasScale = p.inScale != nullptr, hasShift = hasScale && p.inShift != nullptr;
+    const __amdgpu_buffer_rsrc_t scr = __builtin_amdgcn_make_buffer_rsrc((void*)p.inScale, (short)0, hasScale ? p.I * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t shr = __builtin_amdgcn_make_buffer_rsrc((void*)p.inShift, (short)0, hasShift ? p.I * 4 : 0, 0x00020000);
+    float rsc = 0.f, rsh = 0.f;
 
     auto fetch = [&](int ch) {
+        const int cl = ch * KC + (lane & 15);
+        if (hasScale) rsc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(scr, cl * 4, 0, 0));
+        else rsc = cl < p.I ? 1.f : 0.f;
+        if (hasShift) rsh = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(shr, cl * 4, 0, 0));
         const unsigned aoff = aG + (unsigned)ch * (AROW_V * 16);
 #pragma unroll
         for (int q = 0; q < A_PER; q++) {
@@ -268,19 +280,20 @@ conv2d_f16x3_kernel(PlainConvParams p, int* flag) {
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 const int ci = ch * KC + hf * 8 + c;                        // wave-uniform
-                const bool cOk = ci < p.I;
-                const unsigned coff = cOk ? (unsigned)ci * HWb : 0u;
-                const float sc = cOk ? (p.inScale ? p.inScale[ci] : 1.f) : 0.f;
-                const float sh = (cOk && p.inScale && p.inShift) ? p.inShift[ci] : 0.f;
+                const unsigned coff = ci < p.I ? (unsigned)ci * HWb : 0u;
 #pragma unroll
-                for (int q = 0; q < PX_PER; q++) {
-                    const float v = __builtin_fmaf(bufld<float>::ld(xr, bG[q], coff), sc, sh * bM[q]);
-                    rb[q][hf][c] = v;
-                    peak = __builtin_fmaxf(peak, __builtin_fabsf(v));
-                }
+                for (int q = 0; q < PX_PER; q++) rb[q][hf][c] = bufld<float>::ld(xr, bG[q], coff);
             }
     };
     auto stage = [&]() {
+        float sc[2][8], sh[2][8];
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                sc[hf][c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rsc), hf * 8 + c));
+                sh[hf][c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rsh), hf * 8 + c));
+            }
         if (aOk) {
 #pragma unroll
             for (int q = 0; q < A_PER; q++)
@@ -294,7 +307,13 @@ conv2d_f16x3_kernel(PlainConvParams p, int* flag) {
             for (int hf = 0; hf < 2; hf++) {
                 v2h h[4], l[4];
 #pragma unroll
-                for (int c = 0; c < 4; c++) split2(rb[q][hf][2 * c], rb[q][hf][2 * c + 1], h[c], l[c]);
+                for (int c = 0; c < 4; c++) {
+                    // zero padding stays zero: the shift only applies inside the image (bM)
+                    const float v0 = __builtin_fmaf(rb[q][hf][2 * c], sc[hf][2 * c], sh[hf][2 * c] * bM[q]);
+                    const float v1 = __builtin_fmaf(rb[q][hf][2 * c + 1], sc[hf][2 * c + 1], sh[hf][2 * c + 1] * bM[q]);
+                    peak = __builtin_fmaxf(peak, __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)));
+                    split2(v0, v1, h[c], l[c]);
+                }
                 _Float16* dst = sB + (hf * 2) * BPLANE + bL[q];
                 *reinterpret_cast<v8h*>(dst) = __builtin_shufflevector(__builtin_shufflevector(h[0], h[1], 0, 1, 2, 3), __builtin_shufflevector(h[2], h[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
                 *reinterpret_cast<v8h*>(dst + BPLANE) = __builtin_shufflevector(__builtin_shufflevector(l[0], l[1], 0, 1, 2, 3), __builtin_shufflevector(l[2], l[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
