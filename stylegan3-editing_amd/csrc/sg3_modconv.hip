@@ -26,6 +26,10 @@
 #include "sg3_common.h"
 #include "sg3_split.h"
 
+#ifndef SG3_TAILPACK
+#define SG3_TAILPACK 1          // 0 compiles the tap-packed tail chunk of the 3x3 kernel out (A/B builds)
+#endif
+
 namespace sg3 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -45,6 +49,7 @@ struct ConvParams {
     int nch;                         // K chunks = ceil(I / KC)
     int xTiles, yTiles, mTiles;
     int totalBlocks;
+    int tailPack;                    // row-streaming 3x3 kernel: the last K chunk holds at most 4 channels (see the kernel)
 };
 
 template <typename T, int KS, int WM, int WN, int TM, int TN>
@@ -207,7 +212,7 @@ modconv_mfma_kernel(ConvParams p) {
 // three A fragments of that column are held in registers while the patch rows stream through, and one B fragment
 // serves up to three output rows (ky = 0..2): 18 + 6 (TN + 2) ds_read_b128 per 27 TN MFMAs (0.5 per MFMA at TN = 4;
 // a tap-by-tap loop over 2x2 blocks needs 0.67).
-template <typename T, int WM, int WN, int TN, bool SPLIT>
+template <typename T, int WM, int WN, int TN, bool SPLIT, bool PACK>
 __global__ void __launch_bounds__(256, 2)              // two workgroups per CU
 modconv_f16x3_kernel(ConvParams p) {
     constexpr int TM = 1;
@@ -349,56 +354,91 @@ modconv_f16x3_kernel(ConvParams p) {
         for (int r = 0; r < 16; r++)
             d[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, (oL + (r & 3) + 8 * (r >> 2)) * 4, 0, 0));
     }
+    struct BFrag { v8h h, l; };
+    auto load_b = [&](BFrag& f, int pr, int kx) {
+        const _Float16* src = sB + (lh * NPART) * BPLANE + ((wn * TN + pr) * PW + li + kx) * 8;
+        f.h = *reinterpret_cast<const v8h*>(src);
+        if (SPLIT) f.l = *reinterpret_cast<const v8h*>(src + BPLANE);
+    };
+    auto mfma_row = [&](const BFrag& f, const v8h (&ah)[3], const v8h (&al)[3], int pr) {
+        // the three products go round the (up to three) output rows this patch row feeds, so consecutive
+        // MFMAs never wait on each other's accumulator
+        if (SPLIT) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++) { const int b = pr - ky; if (b >= 0 && b < TN) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ky], f.h, acc[0][b], 0, 0, 0); }
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++) { const int b = pr - ky; if (b >= 0 && b < TN) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ky], f.l, acc[0][b], 0, 0, 0); }
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) { const int b = pr - ky; if (b >= 0 && b < TN) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ky], f.h, acc[0][b], 0, 0, 0); }
+    };
+
+    // PACK: the last chunk holds at most 4 channels and is peeled off the loop (below)
+    const int nMain = PACK ? p.nch - 1 : p.nch;
     fetch(0);
-    for (int ch = 0; ch < p.nch; ch++) {
+    for (int ch = 0; ch < nMain; ch++) {
         __syncthreads();
         stage(ch);
         __syncthreads();
         if (ch + 1 < p.nch) fetch(ch + 1);
-        {
-            struct BFrag { v8h h, l; };
-            auto load_b = [&](BFrag& f, int pr, int kx) {
-                const _Float16* src = sB + (lh * NPART) * BPLANE + ((wn * TN + pr) * PW + li + kx) * 8;
-                f.h = *reinterpret_cast<const v8h*>(src);
-                if (SPLIT) f.l = *reinterpret_cast<const v8h*>(src + BPLANE);
-            };
-            auto mfma_row = [&](const BFrag& f, const v8h (&ah)[3], const v8h (&al)[3], int pr) {
-                // the three products go round the (up to three) output rows this patch row feeds, so consecutive
-                // MFMAs never wait on each other's accumulator
-                if (SPLIT) {
 #pragma unroll
-                    for (int ky = 0; ky < 3; ky++) { const int b = pr - ky; if (b >= 0 && b < TN) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ky], f.h, acc[0][b], 0, 0, 0); }
+        for (int kx = 0; kx < 3; kx++) {
+            v8h ah[3], al[3];
 #pragma unroll
-                    for (int ky = 0; ky < 3; ky++) { const int b = pr - ky; if (b >= 0 && b < TN) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ky], f.l, acc[0][b], 0, 0, 0); }
-                }
+            for (int ky = 0; ky < 3; ky++) {
+                const _Float16* src = sA + (wm * 32 + li) * AS + (ky * 3 + kx) * 32 + lh * 8;
+                ah[ky] = *reinterpret_cast<const v8h*>(src);
+                if (SPLIT) al[ky] = *reinterpret_cast<const v8h*>(src + 16);
+            }
+            BFrag b0, b1;
+            load_b(b0, 0, kx);
 #pragma unroll
-                for (int ky = 0; ky < 3; ky++) { const int b = pr - ky; if (b >= 0 && b < TN) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ky], f.h, acc[0][b], 0, 0, 0); }
-            };
-#pragma unroll
-            for (int kx = 0; kx < 3; kx++) {
-                v8h ah[3], al[3];
-#pragma unroll
-                for (int ky = 0; ky < 3; ky++) {
-                    const _Float16* src = sA + (wm * 32 + li) * AS + (ky * 3 + kx) * 32 + lh * 8;
-                    ah[ky] = *reinterpret_cast<const v8h*>(src);
-                    if (SPLIT) al[ky] = *reinterpret_cast<const v8h*>(src + 16);
-                }
-                BFrag b0, b1;
-                load_b(b0, 0, kx);
-#pragma unroll
-                for (int pr = 0; pr < TN + 2; pr += 2) {
-                    if (pr + 1 < TN + 2) load_b(b1, pr + 1, kx);
+            for (int pr = 0; pr < TN + 2; pr += 2) {
+                if (pr + 1 < TN + 2) load_b(b1, pr + 1, kx);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_row(b0, ah, al, pr);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pr + 1 < TN + 2) {
+                    if (pr + 2 < TN + 2) load_b(b0, pr + 2, kx);
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma_row(b0, ah, al, pr);
+                    mfma_row(b1, ah, al, pr + 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (pr + 1 < TN + 2) {
-                        if (pr + 2 < TN + 2) load_b(b0, pr + 2, kx);
-                        __builtin_amdgcn_sched_barrier(0);
-                        mfma_row(b1, ah, al, pr + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                 }
             }
+        }
+    }
+    if (PACK) {
+        // Last chunk with at most 4 channels (I = 81, 51, 323 at FFHQ-1024: 1 or 3 of them): its 16 K slots would carry 4
+        // channels of ONE tap and 12 zeros.  Instead the three column offsets of a filter row share a K step: slots
+        // 0-3 / 4-7 / 8-11 = channels 0-3 of kx = 0 / 1 / 2 (slots 12-15: channels 4-7 of kx = 2, zero in the packed
+        // weights).  Both operands come from the usual LDS images through two 8-byte reads per lane -- two lane-dependent
+        // bases per operand plus immediate offsets -- and the chunk costs 9 TN MFMAs instead of 27 TN.  Peeled off the
+        // loop: inside it, next to the prefetch registers, the extra code path made the whole kernel spill.
+        __syncthreads();
+        stage(p.nch - 1);
+        __syncthreads();
+        typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+        auto two = [](const _Float16* a, const _Float16* b) {
+            return __builtin_shufflevector(*reinterpret_cast<const v4h*>(a), *reinterpret_cast<const v4h*>(b), 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        const _Float16* a0 = sA + (wm * 32 + li) * AS + (lh ? 2 * 32 : 0);
+        const _Float16* a1 = sA + (wm * 32 + li) * AS + (lh ? 2 * 32 + 4 : 32);
+        const _Float16* q0 = sB + (wn * TN * PW + li) * 8 + (lh ? 2 * 8 : 0);      // channel-half 0, hi plane
+        const _Float16* q1 = sB + (wn * TN * PW + li) * 8 + (lh ? 2 * 8 + 4 : 8);
+        v8h ah[3], al[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) {
+            ah[ky] = two(a0 + ky * 96, a1 + ky * 96);
+            if (SPLIT) al[ky] = two(a0 + ky * 96 + 16, a1 + ky * 96 + 16);
+        }
+#pragma unroll
+        for (int pr = 0; pr < TN + 2; pr++) {
+            BFrag f;
+            f.h = two(q0 + pr * PW * 8, q1 + pr * PW * 8);
+            if (SPLIT) f.l = two(q0 + pr * PW * 8 + BPLANE, q1 + pr * PW * 8 + BPLANE);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_row(f, ah, al, pr);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -906,7 +946,7 @@ static int dispatch_conv(const sg3_modconv_params& q, hipStream_t st) {
     }
 }
 
-template <typename T, int WM, int WN, int TN, bool SPLIT>
+template <typename T, int WM, int WN, int TN, bool SPLIT, bool PACK>
 static int launch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     constexpr int BM = WM * 32, ROWS = WN * TN;
     constexpr int PH = ROWS + 2, PW = 34;
@@ -920,7 +960,8 @@ static int launch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     const long long total = (long long)p.xTiles * p.yTiles * p.mTiles * q.N;
     if (total > 0x7fffffffLL) { set_error("modulated_conv2d: grid too large"); return SG3_BAD_ARG; }
     p.totalBlocks = (int)total;
-    auto kern = modconv_f16x3_kernel<T, WM, WN, TN, SPLIT>;
+    p.tailPack = PACK ? 1 : 0;
+    auto kern = modconv_f16x3_kernel<T, WM, WN, TN, SPLIT, PACK>;
     if (ldsBytes > 64 * 1024)
         SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), ldsBytes, st, p);
@@ -936,8 +977,11 @@ static int dispatch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     // small tile wins when it saves at least ~10 % of the rows.
     const int O = q.O;
     const int t32 = ceil_div(O, 32) * 32, t64 = ceil_div(O, 64) * 64;
-    if (O <= 32 || t32 * 10 <= t64 * 9) return launch_conv_f16x3<T, 1, 4, 4, SPLIT>(q, st);      //  32 x (16 rows x 32)
-    return launch_conv_f16x3<T, 2, 2, 4, SPLIT>(q, st);                                            //  64 x (8 rows x 32)
+    // last K chunk with 1..4 channels (and at least one full chunk before it): the kernel packs its taps (PACK)
+    const bool pack = SG3_TAILPACK && q.I > 16 && q.I % 16 >= 1 && q.I % 16 <= 4;
+    if (O <= 32 || t32 * 10 <= t64 * 9)                                                            //  32 x (16 rows x 32)
+        return pack ? launch_conv_f16x3<T, 1, 4, 4, SPLIT, true>(q, st) : launch_conv_f16x3<T, 1, 4, 4, SPLIT, false>(q, st);
+    return pack ? launch_conv_f16x3<T, 2, 2, 4, SPLIT, true>(q, st) : launch_conv_f16x3<T, 2, 2, 4, SPLIT, false>(q, st);   //  64 x (8 rows x 32)
 }
 
 template <typename T, int WM, int WN, int TM, int TN, bool SPLIT>
