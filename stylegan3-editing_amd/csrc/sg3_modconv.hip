@@ -491,8 +491,10 @@ modconv_f16x3_kernel(ConvParams p) {
 // larger along M (128 x 256 pixels, eight waves, wave tile 64 x 64) to keep the L2 -> LDS stream at ~44 FLOP/B, two
 // 16-channel K steps are staged per barrier, and the LDS image is double-buffered: one barrier per 32 input channels.
 // LDS per buffer: A rows of (hi16|lo16) x 2 halfs + 8 halfs of padding; B as planes [k-step][channel-half][hi|lo][pixel][8].
-template <typename T, int WM, int WN, int TM, int TN, bool SPLIT>
-__global__ void __launch_bounds__(512)
+// NBUF = 1: one LDS image (two barriers per stage) so that TWO workgroups fit a CU -- for the thin layers, whose few K
+// stages leave a lone workgroup waiting on HBM at the start and the end of every tile.
+template <typename T, int WM, int WN, int TM, int TN, bool SPLIT, int NBUF>
+__global__ void __launch_bounds__(512, NBUF == 1 ? 4 : 2)      // second argument: waves per SIMD (a workgroup is two per SIMD)
 modconv1_f16x3_kernel(ConvParams p) {
     constexpr int KSUB = 2, KC = 16 * KSUB;
     constexpr int NPART = SPLIT ? 2 : 1;
@@ -636,7 +638,7 @@ modconv1_f16x3_kernel(ConvParams p) {
     stage(smh, 0);
     __syncthreads();
     for (int ch = 0; ch < p.nch; ch++) {
-        const _Float16* cur = smh + (ch & 1) * BUF;
+        const _Float16* cur = smh + (NBUF == 2 ? (ch & 1) * BUF : 0);
         const bool more = ch + 1 < p.nch;
         if (more) fetch(ch + 1);
         if (TM * TN <= 4) {
@@ -654,8 +656,13 @@ modconv1_f16x3_kernel(ConvParams p) {
             load_frags(f, cur, 1);
             mfma_step(f);
         }
-        if (more) stage(smh + ((ch + 1) & 1) * BUF, ch + 1);       // the other buffer: its readers passed the previous barrier
-        __syncthreads();
+        if (NBUF == 2) {
+            if (more) stage(smh + ((ch + 1) & 1) * BUF, ch + 1);   // the other buffer: its readers passed the previous barrier
+            __syncthreads();
+        } else {
+            __syncthreads();                                       // every wave is done reading the image
+            if (more) { stage(smh, ch + 1); __syncthreads(); }
+        }
     }
 
     T* outp = (T*)p.out + (size_t)n * p.O * P;
@@ -984,10 +991,10 @@ static int dispatch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     return pack ? launch_conv_f16x3<T, 2, 2, 4, SPLIT, true>(q, st) : launch_conv_f16x3<T, 2, 2, 4, SPLIT, false>(q, st);   //  64 x (8 rows x 32)
 }
 
-template <typename T, int WM, int WN, int TM, int TN, bool SPLIT>
+template <typename T, int WM, int WN, int TM, int TN, bool SPLIT, int NBUF = 2>
 static int launch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     constexpr int BM = WM * TM * 32, ROWS = WN * TN;
-    constexpr size_t ldsBytes = 2 * ((size_t)BM * (2 * 32 + 8) + (SPLIT ? 8 : 4) * (size_t)ROWS * 32 * 8) * sizeof(_Float16);
+    constexpr size_t ldsBytes = NBUF * ((size_t)BM * (2 * 32 + 8) + (SPLIT ? 8 : 4) * (size_t)ROWS * 32 * 8) * sizeof(_Float16);
     ConvParams p;
     p.x = q.x; p.wp = q.wPacked; p.sIn = q.sIn; p.dcoef = q.dcoef; p.out = q.out;
     p.N = q.N; p.I = q.I; p.O = q.O; p.H = q.H; p.W = q.W; p.pad = 0;
@@ -997,7 +1004,7 @@ static int launch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     const long long total = (long long)p.xTiles * p.yTiles * p.mTiles * q.N;
     if (total > 0x7fffffffLL) { set_error("modulated_conv2d: grid too large"); return SG3_BAD_ARG; }
     p.totalBlocks = (int)total;
-    auto kern = modconv1_f16x3_kernel<T, WM, WN, TM, TN, SPLIT>;
+    auto kern = modconv1_f16x3_kernel<T, WM, WN, TM, TN, SPLIT, NBUF>;
     if (ldsBytes > 64 * 1024)
         SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), ldsBytes, st, p);
@@ -1009,7 +1016,14 @@ template <typename T, bool SPLIT>
 static int dispatch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     // every staged input element is used once per output-channel tile, so the tile is as tall as the channel padding
     // allows: 256 rows (1024 -> 1024 @ 148^2 x 4: 0.88 ms against 1.05 ms with 128 rows and 1.25 ms with 64)
-    if (q.O <= 64) return launch_conv1_f16x3<T, 1, 8, 2, 1, SPLIT>(q, st);        //  64 x 256 pixels
+    // Few K stages (I <= 256: the 532^2 and 1044^2 layers of config R): HBM-bound, and ONE resident workgroup (100 KB of
+    // double-buffered LDS) leaves the CU waiting on memory at the start and end of every tile.  These layers take the
+    // 64-row tile with a single LDS image (42 KB, 110 registers): two workgroups per CU.  Measured at R-1024, batch 8:
+    // L10 256->161 1232 -> 1099 us, L11 161->102 2600 -> 2358, L12 102->64 1373 -> 1103, L13 64->64 945 -> 808 (5.5 TB/s).
+    // The 128-row tile needs 174 registers and spills under the two-workgroup bound.
+    const bool thin = q.I <= 256;
+    if (thin) return launch_conv1_f16x3<T, 1, 8, 2, 1, SPLIT, 1>(q, st);           //  64 x 256 pixels, two workgroups per CU
+    if (q.O <= 64) return launch_conv1_f16x3<T, 1, 8, 2, 1, SPLIT>(q, st);         //  64 x 256 pixels
     const int t128 = ceil_div(q.O, 128) * 128, t256 = ceil_div(q.O, 256) * 256;
     if (t256 <= t128) return launch_conv1_f16x3<T, 2, 4, 4, 2, SPLIT>(q, st);     // 256 x 256 pixels
     return launch_conv1_f16x3<T, 2, 4, 2, 2, SPLIT>(q, st);                       // 128 x 256 pixels
