@@ -209,6 +209,29 @@ typedef struct sg3_bias_act_params {
 SG3_API int sg3_bias_act(const sg3_bias_act_params* p, void* stream);
 
 /* ------------------------------------------------------------------------
+ * fourier_features -- the input features of SynthesisInput.forward
+ *   (models/stylegan3/networks_stylegan3.py:236-241), channels-first:
+ *
+ *   out[n,c,y,x] = sin((grid[y,x,0]*freqs[n,c,0] + grid[y,x,1]*freqs[n,c,1]
+ *                       + phases[n,c]) * 2*pi) * amps[n,c]
+ *
+ * `grid` is the sampling grid the caller built (F.affine_grid, :233-234),
+ * `freqs` / `phases` / `amps` the transformed frequencies, phases and
+ * amplitudes (:222-230).  Operation order as in the reference's torch ops,
+ * so the result is bit-identical to them.  float32 only.
+ * ---------------------------------------------------------------------- */
+typedef struct sg3_fourier_params {
+    const float*   grid;       /* [H,W,2] */
+    const float*   freqs;      /* [N,C,2] */
+    const float*   phases;     /* [N,C] */
+    const float*   amps;       /* [N,C] */
+    float*         out;        /* [N,C,H,W] */
+    int32_t        N, C, H, W;
+} sg3_fourier_params;
+
+SG3_API int sg3_fourier_features(const sg3_fourier_params* p, void* stream);
+
+/* ------------------------------------------------------------------------
  * modulated_conv2d -- replaces the grouped F.conv2d behind
  *   models/stylegan3/networks_stylegan3.py:24-63 (modulated_conv2d), reached
  *   through torch_utils/ops/conv2d_gradfix.py:36-39.

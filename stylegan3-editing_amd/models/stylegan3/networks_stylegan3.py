@@ -25,7 +25,7 @@ import scipy.special
 import torch
 
 from torch_utils import misc, persistence
-from torch_utils.ops import bias_act, filtered_lrelu
+from torch_utils.ops import bias_act, filtered_lrelu, fourier_features
 from torch_utils.ops import modulated_conv as _modconv
 
 
@@ -186,15 +186,17 @@ class SynthesisInput(torch.nn.Module):
         theta[1, 1].mul_(0.5 * self.size[1] / self.sampling_rate)
         grid = torch.nn.functional.affine_grid(theta.unsqueeze(0), [1, 1, self.size[1], self.size[0]], align_corners=False)
 
-        x = (grid.unsqueeze(3) @ freqs.permute(0, 2, 1).unsqueeze(1).unsqueeze(2)).squeeze(3)   # [N,H,W,C]
-        x = torch.sin((x + phases.unsqueeze(1).unsqueeze(2)) * (np.pi * 2)) * amps.unsqueeze(1).unsqueeze(2)
         mix = self.weight / np.sqrt(self.channels)
-        if x.is_cuda and not torch.is_grad_enabled() and (x.shape[1] * x.shape[2]) % 2 == 0:
-            # the channel mix as a 1x1 convolution on the split-precision matrix-core kernel (|features| <= 1): 10 x faster
-            # than the fp32 GEMM the BLAS library picks for this [N*H*W, C] x [C, C] shape, same features bit for bit
-            x = modulated_conv2d(x.permute(0, 3, 1, 2).contiguous(), mix.unsqueeze(2).unsqueeze(3),
-                                 torch.ones([n, self.channels], device=device), demodulate=False, x_bound=1.001)
+        if grid.is_cuda and not torch.is_grad_enabled() and (int(self.size[0]) * int(self.size[1])) % 2 == 0:
+            # GPU inference: the features in one kernel, channels-first and bit-identical to the torch ops below (whose K = 2
+            # matmul is the BLAS library's worst case), then the channel mix as a 1x1 convolution on the split-precision
+            # matrix-core kernel (|features| <= 1): 10 x faster than the fp32 GEMM picked for [N*H*W, C] x [C, C]
+            x = fourier_features.fourier_features(grid[0], freqs, phases, amps)
+            x = modulated_conv2d(x, mix.unsqueeze(2).unsqueeze(3), torch.ones([n, self.channels], device=device),
+                                 demodulate=False, x_bound=1.001)
         else:
+            x = (grid.unsqueeze(3) @ freqs.permute(0, 2, 1).unsqueeze(1).unsqueeze(2)).squeeze(3)   # [N,H,W,C]
+            x = torch.sin((x + phases.unsqueeze(1).unsqueeze(2)) * (np.pi * 2)) * amps.unsqueeze(1).unsqueeze(2)
             x = (x @ mix.t()).permute(0, 3, 1, 2)
         misc.assert_shape(x, [n, self.channels, int(self.size[1]), int(self.size[0])])
         return x

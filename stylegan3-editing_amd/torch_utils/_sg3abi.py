@@ -55,6 +55,11 @@ class ModconvParams(ctypes.Structure):
                 ('N', c_i32), ('I', c_i32), ('O', c_i32), ('H', c_i32), ('W', c_i32), ('k', c_i32), ('pad', c_i32), ('precision', c_i32)]
 
 
+class FourierParams(ctypes.Structure):
+    _fields_ = [('grid', c_vp), ('freqs', c_vp), ('phases', c_vp), ('amps', c_vp), ('out', c_vp),
+                ('N', c_i32), ('C', c_i32), ('H', c_i32), ('W', c_i32)]
+
+
 class ModconvPrepParams(ctypes.Structure):
     _fields_ = [('w', c_vp), ('s', c_vp), ('wPacked', c_vp), ('wsq', c_vp), ('sIn', c_vp), ('dcoef', c_vp),
                 ('inputGain', c_vp), ('inputGainMode', c_i32),
@@ -89,6 +94,7 @@ EXPORTS = [
     ('sg3_bias_act', ctypes.c_int, [ctypes.POINTER(BiasActParams), c_vp]),
     ('sg3_modconv_packed_floats', ctypes.c_int64, [ctypes.c_int] * 4),
     ('sg3_modulated_conv2d', ctypes.c_int, [ctypes.POINTER(ModconvParams), c_vp]),
+    ('sg3_fourier_features', ctypes.c_int, [ctypes.POINTER(FourierParams), c_vp]),
     ('sg3_modulated_conv2d_prep', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), c_vp]),
     ('sg3_modulated_conv2d_prep_batch', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), ctypes.c_int, c_vp]),
     ('sg3_conv2d', ctypes.c_int, [ctypes.POINTER(Conv2dParams), c_vp]),

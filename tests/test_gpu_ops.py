@@ -497,3 +497,23 @@ def test_error_behaviour():
         P.filtered_lrelu(x[0], f, f, b, torch.empty(0), 1, 1, 0, 0, 0, 0, 0, 0, 1.0, 0.2, 256.0, False, False)
     y, so, rc = P.filtered_lrelu(x, torch.ones(3, 3, device=DEV), f, b, torch.empty(0), 1, 1, 1, 1, 1, 1, 0, 0, 1.0, 0.2, 256.0, False, False)
     assert rc == -1 and y.numel() == 0            # no fused kernel: the caller composes the generic path
+
+
+def test_fourier_features_match_torch_ops():
+    """The fused Fourier-feature kernel reproduces the reference's chain of torch ops (K = 2 matmul, + phase, * 2 pi, sin,
+    * amplitude; networks_stylegan3.py:236-241) BIT FOR BIT, for both generator configs' input sizes and a batched transform."""
+    from torch_utils.ops import fourier_features as ff
+    for (n, c, size, sr, bw) in ((3, 64, 36, 16.0, 2.0), (2, 128, 36, 16.0, 2.0), (2, 32, 20, 8.0, 1.5)):
+        g = torch.Generator(device=DEV).manual_seed(n * 100 + c)
+        freqs = torch.randn([n, c, 2], device=DEV, generator=g) * bw
+        phases = torch.rand([n, c], device=DEV, generator=g) - 0.5
+        amps = torch.rand([n, c], device=DEV, generator=g)
+        theta = torch.eye(2, 3, device=DEV)
+        theta[0, 0] = 0.5 * size / sr
+        theta[1, 1] = 0.5 * size / sr
+        grid = torch.nn.functional.affine_grid(theta.unsqueeze(0), [1, 1, size, size], align_corners=False)
+        x = (grid.unsqueeze(3) @ freqs.permute(0, 2, 1).unsqueeze(1).unsqueeze(2)).squeeze(3)
+        ref = (torch.sin((x + phases.unsqueeze(1).unsqueeze(2)) * (np.pi * 2)) * amps.unsqueeze(1).unsqueeze(2)).permute(0, 3, 1, 2)
+        got = ff.fourier_features(grid[0], freqs, phases, amps)
+        assert got.shape == ref.shape
+        assert torch.equal(got, ref.contiguous()), float((got - ref).abs().max())
