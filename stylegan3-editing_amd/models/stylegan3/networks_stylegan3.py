@@ -292,10 +292,11 @@ class SynthesisLayer(torch.nn.Module):
     def compute_dtype(self, force_fp32, device_type):
         return torch.float16 if (self.use_fp16 and not force_fp32 and device_type == 'cuda') else torch.float32
 
-    def conv_spec(self, styles, n, force_fp32):
+    def conv_spec(self, styles, n, force_fp32, input_gain=None):
         """This layer's entry for `modulated_conv.prepare_batch`: everything its convolution's prep work depends on."""
         return dict(w=self.weight, s=styles, demodulate=not self.is_torgb, padding=self.conv_kernel - 1,
-                    input_gain=self.magnitude_ema.rsqrt(), x_bound=getattr(self, 'input_bound', None), n=n,
+                    input_gain=self.magnitude_ema.rsqrt() if input_gain is None else input_gain,
+                    x_bound=getattr(self, 'input_bound', None), n=n,
                     h=int(self.in_size[1]), wd=int(self.in_size[0]), dtype=self.compute_dtype(force_fp32, 'cuda'))
 
     def forward(self, x, w, styles=None, noise_mode='random', force_fp32=False, update_emas=False, prepared=None):
@@ -305,7 +306,7 @@ class SynthesisLayer(torch.nn.Module):
         misc.assert_shape(x, [None, self.in_channels, in_h, in_w])
         if update_emas:
             self._track_magnitude(x)
-        input_gain = self.magnitude_ema.rsqrt()
+        input_gain = self.magnitude_ema.rsqrt() if prepared is None else None      # a prepared convolution carries it
 
         if styles is None:
             misc.assert_shape(w, [x.shape[0], self.w_dim])
@@ -427,7 +428,9 @@ class SynthesisNetwork(torch.nn.Module):
             if styles is None:
                 styles = [layer.styles_from_w(w) for layer, w in zip(layers, per_layer[1:])]
             force_fp32 = bool(layer_kwargs.get('force_fp32', False))
-            prepared = _modconv.prepare_batch([layer.conv_spec(s, int(t_in.shape[0]), force_fp32) for layer, s in zip(layers, styles)])
+            gains = torch.stack([layer.magnitude_ema for layer in layers]).rsqrt()       # one launch for all layers' input gains
+            prepared = _modconv.prepare_batch([layer.conv_spec(s, int(t_in.shape[0]), force_fp32, gains[j:j + 1])
+                                               for j, (layer, s) in enumerate(zip(layers, styles))])
         x = self.input(None, t=t_in)
         for j, layer in enumerate(layers):
             if styles is not None:
