@@ -517,3 +517,28 @@ def test_fourier_features_match_torch_ops():
         got = ff.fourier_features(grid[0], freqs, phases, amps)
         assert got.shape == ref.shape
         assert torch.equal(got, ref.contiguous()), float((got - ref).abs().max())
+
+
+@pytest.mark.parametrize('shape,up,taps,pad,radial', [
+    ((1, 2, 150, 150), 2, 12, [9, 8, 9, 8], False),
+    ((1, 2, 86, 86), 4, 24, [-6, -9, -6, -9], False),
+    ((1, 2, 148, 148), 2, 12, [11, 10, 11, 10], True),
+    ((1, 2, 84, 84), 4, 24, [-2, -5, -2, -5], True),
+])
+@pytest.mark.parametrize('clamp,slope', [(256.0, 0.2), (4.0, 0.2), (None, 0.2), (256.0, 0.0), (8.0, 1.0)])
+def test_filtered_lrelu_nonlinearity_paths(shape, up, taps, pad, radial, clamp, slope):
+    """lrelu + clamp inside the fused kernel on inputs with a quiet part and a band far beyond both clamp bounds (positive
+    and negative), separable and radial down filters; no clamp, slope 0 (relu) and slope 1 as special values."""
+    from oracle import oracle as O
+    fs = 64
+    fu = O.design_lowpass_filter(taps, 4.0, 8.0, fs * up / 2)
+    fd = O.design_lowpass_filter(12, 5.0, 9.0, fs, radial=radial)
+    x = rand(3, *shape); b = rand(4, shape[1])
+    h = shape[2]
+    x[:, :, h // 3: h // 2, :] *= 3000.0                 # far beyond clamp / slope for a band of rows ...
+    x[:, :, :, : shape[3] // 4] *= 40.0                  # ... and moderately large in a band of columns
+    c = dict(up=up, down=2, padding=pad, gain=float(np.sqrt(2)), slope=slope, clamp=clamp, flip=False)
+    y = _flrelu(c, T(x), T(b), T(fu), T(fd))
+    ref = O.filtered_lrelu(x, fu, fd, b, up, 2, pad, c['gain'], slope, clamp, False)
+    assert tuple(y.shape) == ref.shape
+    assert maxabs(y.cpu().numpy(), ref) <= 2e-5 * max(1.0, float(np.abs(ref).max()))
