@@ -50,6 +50,7 @@ struct ConvParams {
     int xTiles, yTiles, mTiles;
     int totalBlocks;
     int tailPack;                    // row-streaming 3x3 kernel: the last K chunk holds at most 4 channels (see the kernel)
+    const float* epBias; float epClamp, epScale;     // ToRGB kernel only: out = clamp(conv + bias[o]) * scale (see sg3_modconv_params)
 };
 
 template <typename T, int KS, int WM, int WN, int TM, int TN>
@@ -747,6 +748,11 @@ modconv_1x1_small_kernel(ConvParams p, int vec) {
                     for (int e = 0; e < 4; e++) acc[o][e] = fmaf(w, xv[e], acc[o][e]); }
             }
             for (int o = 0; o < p.O && o < OMAX; o++) {
+                if (p.epBias) {
+                    const float bo = p.epBias[o];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[o][e] = fminf(fmaxf(acc[o][e] + bo, -p.epClamp), p.epClamp) * p.epScale;
+                }
                 if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(outp + (size_t)o * HW + q * 4) = (f32x4){acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
                 else for (int e = 0; e < 4; e++) io<T>::st(outp + (size_t)o * HW + q * 4 + e, acc[o][e]);
             }
@@ -761,7 +767,10 @@ modconv_1x1_small_kernel(ConvParams p, int vec) {
 #pragma unroll
                 for (int o = 0; o < OMAX; o++) acc[o] = fmaf(sw[i * OMAX + o], xv, acc[o]);
             }
-            for (int o = 0; o < p.O && o < OMAX; o++) io<T>::st(outp + (size_t)o * HW + q, acc[o]);
+            for (int o = 0; o < p.O && o < OMAX; o++) {
+                if (p.epBias) acc[o] = fminf(fmaxf(acc[o] + p.epBias[o], -p.epClamp), p.epClamp) * p.epScale;
+                io<T>::st(outp + (size_t)o * HW + q, acc[o]);
+            }
         }
     }
 }
@@ -773,6 +782,9 @@ static int launch_conv_1x1_small(const sg3_modconv_params& q, hipStream_t st) {
     p.N = q.N; p.I = q.I; p.O = q.O; p.H = q.H; p.W = q.W; p.pad = 0; p.outH = q.H; p.outW = q.W;
     p.nch = ceil_div(q.I, ConvK<1>::KC);
     p.xTiles = p.yTiles = p.mTiles = 1; p.totalBlocks = 0;
+    p.epBias = q.epilogueBias;
+    p.epClamp = q.epilogueClamp >= 0.f ? q.epilogueClamp : INFINITY;
+    p.epScale = q.epilogueScale != 0.f ? q.epilogueScale : 1.f;
     const int HW = q.H * q.W;
     const int vec = (HW % 4 == 0) && (((size_t)q.x | (size_t)q.out) % 16 == 0) ? 1 : 0;
     int bx = ceil_div(vec ? HW / 4 : HW, 256);
@@ -1111,6 +1123,8 @@ int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream) {
     SG3_REQUIRE(p->H + 2 * p->pad - p->k + 1 > 0 && p->W + 2 * p->pad - p->k + 1 > 0, "modulated_conv2d: empty output");
     SG3_REQUIRE(p->dtype == SG3_F32 || p->dtype == SG3_F16, "modulated_conv2d: unsupported dtype");
     hipStream_t st = (hipStream_t)stream;
+    const bool torgb = p->precision == SG3_CONV_FP32 && p->k == 1 && p->pad == 0 && p->O <= 4 && (size_t)p->I * 4 * sizeof(float) <= 48 * 1024;
+    SG3_REQUIRE(!p->epilogueBias || torgb, "modulated_conv2d: the bias / clamp / scale epilogue exists for the ToRGB kernel only (1x1, O <= 4, fp32 form)");
     if (p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16) {
         SG3_REQUIRE(p->dcoef, "modulated_conv2d: f16x3 needs dcoef");
         SG3_REQUIRE(p->k == 3 || p->pad == 0, "modulated_conv2d: f16x3 1x1 kernels take no padding");
@@ -1124,7 +1138,7 @@ int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream) {
         return p->dtype == SG3_F32 ? dispatch_conv_f16x3<float, true>(*p, st) : dispatch_conv_f16x3<_Float16, true>(*p, st);
     }
     SG3_REQUIRE(p->precision == SG3_CONV_FP32, "modulated_conv2d: bad precision");
-    if (p->k == 1 && p->pad == 0 && p->O <= 4 && (size_t)p->I * 4 * sizeof(float) <= 48 * 1024)
+    if (torgb)
         return p->dtype == SG3_F32 ? launch_conv_1x1_small<float>(*p, st) : launch_conv_1x1_small<_Float16>(*p, st);
     if (p->dtype == SG3_F32) return p->k == 3 ? dispatch_conv<float, 3>(*p, st) : dispatch_conv<float, 1>(*p, st);
     return p->k == 3 ? dispatch_conv<_Float16, 3>(*p, st) : dispatch_conv<_Float16, 1>(*p, st);

@@ -51,14 +51,14 @@ def _summary(module, *rows):
 
 
 @misc.profiled_function
-def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, x_bound=None, prepared=None):
+def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, x_bound=None, prepared=None, epilogue=None):
     """x [N,I,H,W], w [O,I,kh,kw], s [N,I], input_gain [] | [I] | [N,I]  ->  [N,O,H',W'].
 
     Equals a per-sample convolution with weights  w * s[n] (unit-normalised and demodulated when `demodulate`) times
     `input_gain` (reference :24-63).  `x_bound` is an extension: a guaranteed bound on |x| that lets the HIP kernel use
     its split-precision matrix-core path (torch_utils/ops/modulated_conv.py)."""
     return _modconv.modulated_conv2d(x, w, s, demodulate=demodulate, padding=padding, input_gain=input_gain, x_bound=x_bound,
-                                     prepared=prepared)
+                                     prepared=prepared, epilogue=epilogue)
 
 
 
@@ -299,6 +299,12 @@ class SynthesisLayer(torch.nn.Module):
                     x_bound=getattr(self, 'input_bound', None), n=n,
                     h=int(self.in_size[1]), wd=int(self.in_size[0]), dtype=self.compute_dtype(force_fp32, 'cuda'))
 
+    def fuses_output(self, dtype):
+        """ToRGB in inference: bias and clamp -- the layer's whole filtered_lrelu (up = down = 1, no filters, gain = slope = 1,
+        no padding) -- fold into the convolution's stores; the layer's output is unchanged, one pass over the image is saved."""
+        return (self.is_torgb and self.up_factor == 1 and self.down_factor == 1 and self.up_filter is None and self.down_filter is None
+                and not any(self.padding) and _modconv.torgb_epilogue_ok(self.weight, self.conv_kernel - 1, dtype))
+
     def forward(self, x, w, styles=None, noise_mode='random', force_fp32=False, update_emas=False, prepared=None):
         assert noise_mode in ['random', 'const', 'none']  # kept for API compatibility; SG3 has no noise inputs
         in_w, in_h = (int(v) for v in self.in_size)
@@ -313,9 +319,15 @@ class SynthesisLayer(torch.nn.Module):
             styles = self.styles_from_w(w)
 
         dtype = self.compute_dtype(force_fp32, x.device.type)
+        epilogue = None
+        if prepared is not None and self.fuses_output(dtype):
+            epilogue = (self.bias, self.conv_clamp, 1.0)       # clamp(conv + bias) inside the convolution
         x = modulated_conv2d(x=x.to(dtype), w=self.weight, s=styles, padding=self.conv_kernel - 1,
                              demodulate=(not self.is_torgb), input_gain=input_gain, x_bound=getattr(self, 'input_bound', None),
-                             prepared=prepared)
+                             prepared=prepared, epilogue=epilogue)
+        if epilogue is not None:
+            misc.assert_shape(x, [None, self.out_channels, out_h, out_w])
+            return x
         x = filtered_lrelu.filtered_lrelu(
             x=x, fu=self.up_filter, fd=self.down_filter, b=self.bias.to(x.dtype), up=self.up_factor, down=self.down_factor,
             padding=self.padding, gain=(1 if self.is_torgb else np.sqrt(2)), slope=(1 if self.is_torgb else 0.2), clamp=self.conv_clamp)

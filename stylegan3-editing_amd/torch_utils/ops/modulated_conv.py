@@ -131,11 +131,12 @@ def prepare_batch(specs):
     return plans
 
 
-def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None, x_bound_dev=None, out_scale=None, prepared=None):
+def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None, x_bound_dev=None, out_scale=None, prepared=None, epilogue=None):
     """prep + implicit-GEMM kernels.  Returns (out, sIn [N,I], dcoef [N,O] or None): the two per-sample scale vectors are
     what the data-gradient pass needs.  `x_bound_dev`: one-element device tensor holding the bound; `out_scale` [N,O]: extra
     per-sample output-channel scale folded into the epilogue coefficient; `prepared`: the outcome of `prepare_batch` for
-    exactly this call (then no prep kernel is launched here)."""
+    exactly this call (then no prep kernel is launched here); `epilogue` = (bias [O] float32, clamp or None, scale): the ToRGB
+    kernel's fused  clamp(out + bias) * scale  (see `torgb_epilogue_ok`)."""
     n, ci, h, wd = (int(v) for v in x.shape)
     co, ci2, k, _ = (int(v) for v in w.shape)
     if ci != ci2:
@@ -161,6 +162,10 @@ def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None, x_bound_dev=
         cp.dtype = abi.dtype_code(x.dtype)
         cp.N, cp.I, cp.O, cp.H, cp.W, cp.k, cp.pad = n, ci, co, h, wd, k, int(padding)
         cp.precision = pr.prec
+        if epilogue is not None:
+            bias, clamp, scale = epilogue
+            bias = bias.detach().to(device=dev, dtype=torch.float32).contiguous()
+            cp.epilogueBias, cp.epilogueClamp, cp.epilogueScale = abi.ptr(bias), float(-1.0 if clamp is None else clamp), float(scale)
         abi.check(lib.sg3_modulated_conv2d(ctypes.byref(cp), stream), 'sg3_modulated_conv2d')
     return out, pr.s_in, pr.dcoef
 
@@ -215,8 +220,8 @@ def _weight_gradient(x, dy, k, padding, x_amax=None, dy_amax=None):
 
 class _ModulatedConv2dHip(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, s, input_gain, demodulate, padding, x_bound, prepared=None):  # pylint: disable=arguments-differ
-        out, s_in, dcoef = _launch(x, w, s, demodulate, padding, input_gain, x_bound, prepared=prepared)
+    def forward(ctx, x, w, s, input_gain, demodulate, padding, x_bound, prepared=None, epilogue=None):  # pylint: disable=arguments-differ
+        out, s_in, dcoef = _launch(x, w, s, demodulate, padding, input_gain, x_bound, prepared=prepared, epilogue=epilogue)
         ctx.save_for_backward(x, w, s, input_gain if input_gain is not None else torch.empty(0), s_in,
                               dcoef if dcoef is not None else torch.empty(0))
         ctx.cfg = (demodulate, padding, input_gain is not None)
@@ -228,7 +233,7 @@ class _ModulatedConv2dHip(torch.autograd.Function):
         x, w, s, g, s_in, dcoef = ctx.saved_tensors
         demodulate, padding, has_gain = ctx.cfg
         need = ctx.needs_input_grad
-        out = [None] * 8
+        out = [None] * 9
         if torch.is_grad_enabled():
             # higher-order gradients: differentiate the reference formulation itself
             ins, idx = [], []
@@ -270,11 +275,19 @@ class _ModulatedConv2dHip(torch.autograd.Function):
         return tuple(out)
 
 
+def torgb_epilogue_ok(w, padding, dtype):
+    """True when a call with these weights runs on the ToRGB kernel (1x1, at most 4 output channels, float32), the one
+    kernel that can fuse  clamp(out + bias) * scale  into its stores."""
+    co, ci, k, _ = (int(v) for v in w.shape)
+    return k == 1 and int(padding) == 0 and co <= 4 and ci * 16 <= 48 * 1024 and dtype == torch.float32
+
+
 @misc.profiled_function
-def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, impl='cuda', x_bound=None, prepared=None):
+def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, impl='cuda', x_bound=None, prepared=None, epilogue=None):
     """x [N,I,H,W], w [O,I,k,k], s [N,I]; input_gain [], [I] or [N,I].  Returns [N,O,H+2p-k+1,W+2p-k+1] in x.dtype.
     `x_bound` (optional float): a guaranteed upper bound on |x|; enables the split-precision MFMA path (see `precision`).
-    `prepared` (optional): this call's entry of `prepare_batch`, made from the same w, s, input_gain and x_bound."""
+    `prepared` (optional): this call's entry of `prepare_batch`, made from the same w, s, input_gain and x_bound.
+    `epilogue` (optional, inference only): (bias, clamp, scale) fused into the ToRGB kernel, see `torgb_epilogue_ok`."""
     assert impl in ['ref', 'cuda']
     with misc.suppress_tracer_warnings():
         n = int(x.shape[0])
@@ -283,5 +296,7 @@ def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, impl=
     misc.assert_shape(x, [n, i, None, None])
     misc.assert_shape(s, [n, i])
     if impl == 'cuda' and x.device.type == 'cuda':
-        return _ModulatedConv2dHip.apply(x, w, s, input_gain, bool(demodulate), int(padding), x_bound, prepared)
+        if epilogue is not None and (torch.is_grad_enabled() or not torgb_epilogue_ok(w, padding, x.dtype)):
+            raise RuntimeError('modulated_conv2d: the fused epilogue is for ToRGB-shaped inference calls only')
+        return _ModulatedConv2dHip.apply(x, w, s, input_gain, bool(demodulate), int(padding), x_bound, prepared, epilogue)
     return _composite(x, w, s, demodulate, padding, input_gain)

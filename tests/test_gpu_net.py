@@ -184,3 +184,23 @@ def test_batched_prep_matches_per_layer_prep():
     x = torch.randn(2, layer.in_channels, int(layer.in_size[1]) + 2, int(layer.in_size[0]), device='cuda:0')
     with pytest.raises(RuntimeError, match='prepared for'):
         mc.modulated_conv2d(x, layer.weight, spec['s'], padding=spec['padding'], input_gain=spec['input_gain'], x_bound=1e3, prepared=pr)
+
+
+def test_torgb_epilogue_fused_and_refused():
+    """The ToRGB convolution fuses bias + clamp (+ scale) into its stores: identical to conv -> filtered_lrelu(up = down = 1,
+    gain = slope = 1) -> scale.  Other convolution shapes refuse the epilogue (C ABI and Python wrapper)."""
+    from torch_utils.ops import filtered_lrelu as fl
+    from torch_utils.ops import modulated_conv as mc
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn([2, 32, 64, 64], device=DEV, generator=g) * 50
+    w = torch.randn([3, 32, 1, 1], device=DEV, generator=g)
+    s = torch.randn([2, 32], device=DEV, generator=g) + 1
+    b = torch.randn([3], device=DEV, generator=g) * 10
+    with torch.no_grad():
+        plain = mc.modulated_conv2d(x, w, s, demodulate=False, padding=0, input_gain=torch.tensor(0.7, device=DEV))
+        want = fl.filtered_lrelu(plain, b=b, up=1, down=1, padding=0, gain=1, slope=1, clamp=40.0) * 0.25
+        got = mc.modulated_conv2d(x, w, s, demodulate=False, padding=0, input_gain=torch.tensor(0.7, device=DEV), epilogue=(b, 40.0, 0.25))
+        assert torch.equal(got, want) and float(want.abs().max()) == 10.0          # the clamp binds somewhere
+        w3 = torch.randn([8, 32, 3, 3], device=DEV, generator=g)
+        with pytest.raises(RuntimeError, match='ToRGB'):
+            mc.modulated_conv2d(x, w3, s, padding=2, epilogue=(torch.zeros(8, device=DEV), 40.0, 1.0))
