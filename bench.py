@@ -47,11 +47,15 @@ def build_generator(cfg, device):
 
 
 def flrelu_algorithmic_bytes(G, batch, elem_size=4):
-    """Sum over synthesis layers of C_out * (in^2 + out^2) * sizeof (read conv output once, write activation once)."""
+    """Sum over the synthesis layers that launch filtered_lrelu of C_out * (in^2 + out^2) * sizeof (read the convolution's
+    output once, write the activation once).  The ToRGB layer's bias + clamp ride in its convolution in inference: no launch,
+    no bytes."""
     total = 0
     per_layer = {}
     for name in G.synthesis.layer_names:
         layer = getattr(G.synthesis, name)
+        if layer.fuses_output(torch.float32):
+            continue
         k = layer.conv_kernel
         ins = int(layer.in_size[0]) + k - 1
         outs = int(layer.out_size[0])
@@ -335,13 +339,13 @@ def main():
         extras = bench_extras(G, ws, device)
 
     if rank == 0:
-        total_bytes, _ = flrelu_algorithmic_bytes(G, args.batch)
         n_layers = len(G.synthesis.layer_names)
-        fl_ms = timer.median_step_ms('filtered_lrelu', n_layers)         # per step, all 15 launches
+        total_bytes, fl_layers = flrelu_algorithmic_bytes(G, args.batch)
+        fl_ms = timer.median_step_ms('filtered_lrelu', len(fl_layers))    # per step: the 14 streaming launches
         # 16 convolution launches per step: the channel mix of the Fourier-feature input runs on the 1x1 kernel too
         conv_ms = timer.median_step_ms('modulated_conv2d', n_layers + 1)
         achieved = total_bytes / (fl_ms * 1e-3) / 1e9 if fl_ms > 0 else 0.0
-        # HBM traffic of the same 15 launches from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes over this
+        # HBM traffic of the same 14 launches from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes over this
         # command, summarised by tools/sum_traffic.py); only valid for the default workload
         traffic = None
         tfile = os.path.join(ROOT, 'profiles', 'flrelu_traffic.json')
@@ -362,7 +366,7 @@ def main():
             'config': {'workload': f'StyleGAN3-T FFHQ-1024 Generator.synthesis forward, batch {args.batch} per GPU, force_fp32 '
                                    f'(BASELINE configs[1]); seeded random weights', 'per_gpu_batch': args.batch, 'sharding': 'images',
                        'launch': 'eager' if args.eager else 'hipGraph replay'},
-            'roofline': {'bound': 'hbm', 'kernel': 'flrelu_stream_kernel (+pointwise ToRGB)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            'roofline': {'bound': 'hbm', 'kernel': 'flrelu_stream_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_step': total_bytes, 'kernel_ms_per_step': fl_ms},
             # second roofline, same shape: the modulated convolutions against the dense fp16 MFMA peak.  `achieved` counts the
