@@ -1000,6 +1000,16 @@ static int dispatch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     const bool pack = SG3_TAILPACK && q.I > 16 && q.I % 16 >= 1 && q.I % 16 <= 4;
     if (O <= 32 || t32 * 10 <= t64 * 9)                                                            //  32 x (16 rows x 32)
         return pack ? launch_conv_f16x3<T, 1, 4, 4, SPLIT, true>(q, st) : launch_conv_f16x3<T, 1, 4, 4, SPLIT, false>(q, st);
+    if (!pack) {
+        // Small grids (the 36^2 .. 52^2 layers): 512 workgroups are resident at once, so the time goes with the number of
+        // ROUNDS times the rows a workgroup computes.  Ten-row tiles turn the 640 workgroups of a 38-row output (8 images
+        // x 8 channel tiles x 2 x 5) into exactly 512: one round of 5 rows per wave instead of two rounds of 4.
+        const int outH = q.H + 2 * q.pad - 2, outW = q.W + 2 * q.pad - 2;
+        const long long per = (long long)q.N * ceil_div(O, 64) * ceil_div(outW, 32);
+        const long long wg8 = per * ceil_div(outH, 8), wg10 = per * ceil_div(outH, 10);
+        if (wg8 <= 2048 && ceil_div64(wg10, 512) * 5 < ceil_div64(wg8, 512) * 4)
+            return launch_conv_f16x3<T, 2, 2, 5, SPLIT, false>(q, st);                             //  64 x (10 rows x 32)
+    }
     return pack ? launch_conv_f16x3<T, 2, 2, 4, SPLIT, true>(q, st) : launch_conv_f16x3<T, 2, 2, 4, SPLIT, false>(q, st);   //  64 x (8 rows x 32)
 }
 

@@ -358,7 +358,8 @@ def test_modulated_conv2d_plane_beyond_descriptor_offsets(k):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize('n,ci,co,h', [(2, 323, 203, 22), (1, 128, 81, 40), (2, 51, 32, 70), (2, 512, 512, 12), (1, 203, 128, 37), (3, 81, 51, 50)])
+@pytest.mark.parametrize('n,ci,co,h', [(2, 323, 203, 22), (1, 128, 81, 40), (2, 51, 32, 70), (2, 512, 512, 12), (1, 203, 128, 37), (3, 81, 51, 50),
+                                      (4, 16, 832, 36)])        # the last one: 520 eight-row tiles -> the ten-row tile (one round of 416)
 def test_modulated_conv2d_split_precision(n, ci, co, h):
     """fp16 hi/lo split on the fp16 matrix cores (x_bound given) is fp32-equivalent: compared with the fp64 result of
     the oracle, its error is of the same order as the exact-fp32 MFMA kernel's.  Also large styles (power-of-two
