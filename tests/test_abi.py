@@ -38,7 +38,8 @@ def test_struct_layout_matches_header():
     for cname, cls in (('sg3_filtered_lrelu_params', _sg3abi.FilteredLreluParams), ('sg3_filtered_lrelu_act_params', _sg3abi.FilteredLreluActParams),
                        ('sg3_upfirdn2d_params', _sg3abi.Upfirdn2dParams), ('sg3_bias_act_params', _sg3abi.BiasActParams),
                        ('sg3_modconv_params', _sg3abi.ModconvParams), ('sg3_modconv_prep_params', _sg3abi.ModconvPrepParams),
-                       ('sg3_conv2d_params', _sg3abi.Conv2dParams)):
+                       ('sg3_conv2d_params', _sg3abi.Conv2dParams), ('sg3_wgrad_params', _sg3abi.WgradParams),
+                       ('sg3_fourier_params', _sg3abi.FourierParams)):
         body = re.search(r'typedef struct ' + cname + r' \{(.*?)\} ' + cname + ';', src, re.S).group(1)
         body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
         names = []
