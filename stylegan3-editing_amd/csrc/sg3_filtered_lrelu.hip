@@ -37,6 +37,12 @@
 #include "sg3_common.h"
 #include <cmath>
 
+// rows of input the streaming kernel keeps in flight per wave (each costs NL registers per lane): three rows are ~3 x 1.5 us
+// of work, several HBM latencies
+#ifndef SG3_PREFETCH_ROWS
+#define SG3_PREFETCH_ROWS 3
+#endif
+
 namespace sg3 {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -213,13 +219,13 @@ struct WaveState {
     v2f w[6][2];                  // sliding window of H-upsampled rows: [slot][column pair]
     v2f xw[6][4];                 // 2-D up filter: sliding window of RAW input rows, 8 samples per lane as adjacent pairs
     v2f acc[6][2];                // output rows in flight: [slot][column pair]
-    float pre[6][Cfg::NL];        // prefetched input samples (+bias) for the next 6 rows
+    float pre[SG3_PREFETCH_ROWS][Cfg::NL];   // prefetched input samples (+bias) for the next rows
     float bcol[Cfg::NL];          // bias where this lane's input column exists, else 0
     int coff[Cfg::NL];            // byte offset of this lane's input columns inside a row
     v2f tuP[Cfg::FU / 2];         // up taps (x U) in REVERSED pairs (tu[2m+1], tu[2m]): the H-up column-pair operands
                                   // as they stand, and the source of the V-up tap splats (odd tap = low half)
     v2f tdP[Cfg::FD / 2];         // down taps (td[2m], td[2m+1]): V-down splats and H-down even/odd pairs
-    unsigned sg[6][U];            // sign-read mode: prefetched sign bytes (this lane's byte | next byte << 8) per upsampled row
+    unsigned sg[SG3_PREFETCH_ROWS][U];       // sign-read mode: prefetched sign bytes (this lane's byte | next byte << 8) per upsampled row
     float osum;                   // running sum of the outputs this lane stored (only kept when p.ysum is given)
     int soff;                     // sign modes: byte offset, inside a sign row, of the byte holding this lane's first column
     int sq;                       // sign modes: position (0..3) of that column inside its byte (wave-uniform)
@@ -267,12 +273,13 @@ struct Stream {
         constexpr bool UP2D = RADIAL == 3 || RADIAL == 4;          // full 12x12 UP filter (adjoint of those layers)
         // ---- input row -> LDS -> this lane's H-upsampled samples ----
         wave_lds_sync();                 // the previous row's sIn reads precede this row's writes
+        constexpr int PS = S % SG3_PREFETCH_ROWS;        // prefetch slot of this row
 #pragma unroll
-        for (int q = 0; q < Cfg::NL; q++) sIn[lane + 64 * q] = st.pre[S][q];
+        for (int q = 0; q < Cfg::NL; q++) sIn[lane + 64 * q] = st.pre[PS][q];
         unsigned sgNow[U];               // this row's sign bytes: the prefetch below reuses their slot
 #pragma unroll
-        for (int j = 0; j < U; j++) sgNow[j] = SIGNS == 2 ? st.sg[S][j] : 0u;
-        prefetch(st, S, p, plane, splane, i + 6);
+        for (int j = 0; j < U; j++) sgNow[j] = SIGNS == 2 ? st.sg[PS][j] : 0u;
+        prefetch(st, PS, p, plane, splane, i + SG3_PREFETCH_ROWS);
         wave_lds_sync();
         if (U == 2) {
             float xs[8];
@@ -632,7 +639,7 @@ struct Stream {
 #pragma unroll
             for (int q = 0; q < 4; q++) st.xw[s][q] = splat(0.f);
             st.acc[s][0] = splat(0.f); st.acc[s][1] = splat(0.f);
-            prefetch(st, s, p, plane, splane, iFirst + s);
+            if (s < SG3_PREFETCH_ROWS) prefetch(st, s, p, plane, splane, iFirst + s);
         }
 
         int i = iFirst;
