@@ -24,7 +24,7 @@
 //   output row, and because a wave only talks to itself there is no s_barrier anywhere (LDS executes a wave's
 //   DS instructions in order; the compiler is held back with wavefront-scope fences).  The window / accumulator
 //   rotation is resolved at compile time by unrolling 6 input rows per loop iteration.
-//   Global reads are issued 6 rows ahead into registers; reads and writes are 256-B contiguous per instruction.
+//   Global reads are issued 3 rows ahead into registers; reads and writes are 256-B contiguous per instruction.
 //   Grid = planes x row-chunks x strips, renumbered so that blocks sharing halo columns/rows sit on one XCD (L2).
 //
 // Supported by the streaming kernel (everything the StyleGAN3 forward needs): separable fu/fd with
