@@ -17,6 +17,8 @@ One JSON line is printed by rank 0:
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -236,7 +238,61 @@ def bench_extras(G, ws, device, steps=5):
     return out
 
 
-def main():
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: start the N ranks as FRESH child processes
+    (torch.distributed.run, one rank per GPU, RCCL), relay rank 0's single JSON line and the children's exit status.  This
+    parent has not touched the GPU (no HIP call, no torch.cuda.is_available()) and never execs: it only waits."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault('OMP_NUM_THREADS', '8')
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)          # stderr passes through
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or len(lines) != 1:
+        print(f'[bench] {args.gpus}-rank launch failed: exit code {proc.returncode}, {len(lines)} result lines', file=sys.stderr, flush=True)
+        return proc.returncode or 1
+    print(lines[0], flush=True)
+    return 0
+
+
+def dry_run(args, rank, world):
+    """CPU rehearsal of the multi-rank launch path (gloo, no GPU, a stub in place of the synthesis step): exercises the
+    launcher, the rendezvous, the barrier / MAX-over-ranks timing and the one-line output.  Not a measurement: `value` is null."""
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    x = torch.full([4], float(rank))
+    for _ in range(args.warmup):
+        x = x * 1.0
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = x + 1.0
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    seen = torch.tensor([float(rank)])
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({'metric': 'DRY RUN (launch path rehearsal on CPU, gloo) -- not a measurement', 'value': None, 'unit': 'imgs/s',
+                          'n_gpus': world, 'world_size_observed': dist.get_world_size() if world > 1 else 1, 'rank_sum': float(seen.item()),
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': float(t.item()) / max(args.steps, 1) * 1e3, 'dry_run': True}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
@@ -247,11 +303,20 @@ def main():
     ap.add_argument('--no-inversion', action='store_true', help='skip the secondary ReStyle inversion measurement')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a captured hipGraph')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary mixed-precision / config-R measurements')
-    args = ap.parse_args()
+    ap.add_argument('--dry-run', action='store_true', help='CPU rehearsal of the launch path (gloo, stub step); prints a line with value null')
+    args = ap.parse_args(argv)
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # the driver's scaling run calls `python bench.py --gpus N` directly: this process becomes the launcher (before any GPU use)
+        sys.exit(launch_ranks(args, argv))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; run `python bench.py --gpus {args.gpus} ...` (it starts the ranks itself) or '
+                 f'`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`')
+    if args.dry_run:
+        return dry_run(args, rank, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the product has no CPU fallback for the timed path)'
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
@@ -361,7 +426,7 @@ def main():
         conv_tflops = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         out = {
             'metric': 'FFHQ-1024 StyleGAN3-T synthesis imgs/sec', 'value': args.batch * world * args.steps / dt, 'unit': 'imgs/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'n_gpus': world, 'world_size_observed': dist.get_world_size() if world > 1 else 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'StyleGAN3-T FFHQ-1024 Generator.synthesis forward, batch {args.batch} per GPU, force_fp32 '
                                    f'(BASELINE configs[1]); seeded random weights', 'per_gpu_batch': args.batch, 'sharding': 'images',

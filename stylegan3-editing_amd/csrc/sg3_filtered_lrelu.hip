@@ -67,7 +67,13 @@ struct StreamParams {
     float* ysum;                   // optional [N*C][nChunks*nStrips]: sum of this block's outputs (adjoint passes only: their bias gradient)
     unsigned char* s;              // sign tensor [N*C][sH][sWb] (2 bits per upsampled sample, 4 per byte), or null
     int sH, sWb, sx, sy;           // rows, bytes per row, offset of the upsampled buffer inside the sign tensor
+#ifdef SG3_STAMPS
+    unsigned long long* stamps;    // diagnostic build (tools/flrelu_clock.hip): per block {shader cycles, 100 MHz ticks} of the wave's life
+#endif
 };
+#ifdef SG3_STAMPS
+static unsigned long long* g_stamps = nullptr;
+#endif
 
 __device__ __forceinline__ int to_sgpr_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float to_sgpr(float v) {
@@ -559,6 +565,9 @@ struct Stream {
         lds_f* sIn = (lds_f*)lds;
         lds_f* sOut = (lds_f*)lds + Cfg::SIN;                               // row exchanged for the horizontal down pass
         const int lane = threadIdx.x;
+#ifdef SG3_STAMPS
+        const unsigned long long stampC = __builtin_amdgcn_s_memtime(), stampR = __builtin_amdgcn_s_memrealtime();
+#endif
 
         // XCD-aware renumbering: consecutive logical blocks (adjacent strips / chunks of one plane) share an XCD's L2
         int bid = blockIdx.x;
@@ -659,6 +668,12 @@ struct Stream {
                     for (int h = 0; h < 2; h++) { const v2f t = st.acc[r][h]; st.acc[r][h] = st.acc[r + 3][h]; st.acc[r + 3][h] = t; }
             }
         }
+#ifdef SG3_STAMPS
+        if (p.stamps && lane == 0) {
+            p.stamps[2 * (long long)blockIdx.x] = __builtin_amdgcn_s_memtime() - stampC;
+            p.stamps[2 * (long long)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - stampR;
+        }
+#endif
         if (SIGNS == 2 && p.ysum) {                         // bias gradient of the adjoint pass
             float v = st.osum;
 #pragma unroll
@@ -765,6 +780,9 @@ static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
 
     p.s = q.s; p.sH = q.sH; p.sWb = q.sWbytes; p.sx = q.sx; p.sy = q.sy;
     p.ysum = q.ySumPartial;
+#ifdef SG3_STAMPS
+    p.stamps = g_stamps;
+#endif
     stream_grid(q.N, q.C, q.yH, q.yW, q.down, p.nStrips, p.TW, p.nChunks, p.CH);
     const long long planes = (long long)q.N * q.C;
     const long long total = planes * p.nStrips * p.nChunks;
