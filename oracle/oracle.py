@@ -498,6 +498,109 @@ def backbone_encoder(sd, x, num_layers=50, n_styles=16, return_feats=False):
     return (codes, feats) if return_feats else codes
 
 
+def _style_heads(sd, h, n_styles):
+    """map2style.py:8-25 for every head on the trunk output h [N,512,16,16]; stacked (restyle_psp_encoders.py:46-50, :93-97)."""
+    codes = []
+    for j in range(n_styles):
+        t = h
+        for c in (0, 2, 4, 6):
+            t = conv2d(t, sd[f'styles.{j}.convs.{c}.weight'], sd[f'styles.{j}.convs.{c}.bias'], 2, 1)
+            t = np.where(t >= 0, t, t * np.float32(0.01)).astype(np.float32)
+        t = t.reshape(-1, t.shape[1])
+        w = sd[f'styles.{j}.linear.weight'] * np.float32(1.0 / np.sqrt(t.shape[1]))
+        codes.append(t @ w.T + sd[f'styles.{j}.linear.bias'][None])
+    return np.stack(codes, axis=1).astype(np.float32)
+
+
+def resnet_backbone_encoder(sd, x, n_styles=16, return_feats=False):
+    """models/setgan/encoder/encoders/restyle_psp_encoders.py:53-97 (eval): conv7x7 s2 + BN + PReLU, then resnet34's layer1..4
+    flattened into `body` -- torchvision BasicBlock: relu(bn2(conv2(relu(bn1(conv1(x))))) + (downsample(x) | x)), conv1 strided
+    (torchvision is absent here; its BasicBlock.forward is restated from the published definition) -- then the style heads."""
+    h = conv2d(x, sd['conv1.weight'], None, 2, 3)
+    h = _prelu(_bn(h, sd, 'bn1.'), sd['relu.weight'])
+    feats = {'stem': h}
+    i = 0
+    for planes, count, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)):
+        for u in range(count):
+            p, st = f'body.{i}.', (stride if u == 0 else 1)
+            r = np.maximum(_bn(conv2d(h, sd[p + 'conv1.weight'], None, st, 1), sd, p + 'bn1.'), 0)
+            r = _bn(conv2d(r, sd[p + 'conv2.weight'], None, 1, 1), sd, p + 'bn2.')
+            if p + 'downsample.0.weight' in sd:
+                h = _bn(conv2d(h, sd[p + 'downsample.0.weight'], None, st, 0), sd, p + 'downsample.1.')
+            h = np.maximum(r + h, 0).astype(np.float32)
+            feats[f'body{i}'] = h
+            i += 1
+    codes = _style_heads(sd, h, n_styles)
+    return (codes, feats) if return_feats else codes
+
+
+# ----------------------------------------------------------------------------
+# ReStyle wrapper and loop (SURVEY 8a14 / 8f1).  Restated from the reference text: psp3.py / inference_utils.py import
+# torchvision / pyrallis (absent here), so these are pinned by this restatement; the encoder and the synthesis under them
+# are pinned by reference-generated fixtures.
+
+def adaptive_avg_pool(x, out_hw=(256, 256)):
+    """torch.nn.AdaptiveAvgPool2d (psp3.py:18 `face_pool`): bin i covers [floor(i*n/o), ceil((i+1)*n/o))."""
+    n, c, h, w = x.shape
+    oh, ow = out_hw
+    if (h, w) == (oh, ow):
+        return x.astype(np.float32)
+    def bins(n_in, n_out):
+        return [(int(np.floor(i * n_in / n_out)), int(np.ceil((i + 1) * n_in / n_out))) for i in range(n_out)]
+    if h % oh == 0 and w % ow == 0:                       # equal bins: a reshape-mean
+        return x.reshape(n, c, oh, h // oh, ow, w // ow).mean(axis=(3, 5), dtype=np.float64).astype(np.float32)
+    rows = np.stack([x[:, :, a:b, :].mean(axis=2, dtype=np.float64) for a, b in bins(h, oh)], axis=2)
+    return np.stack([rows[:, :, :, a:b].mean(axis=3) for a, b in bins(w, ow)], axis=3).astype(np.float32)
+
+
+def psp_forward(enc_sd, gen_sd, sched, x, latent=None, latent_avg=None, resize=True, input_code=False, landmarks_transform=None):
+    """models/setgan/encoder/psp3.py:45-84.  Returns (aligned images, unaligned images or None, codes)."""
+    if input_code:
+        codes = x.astype(np.float32)
+    else:
+        codes = backbone_encoder(enc_sd, x)
+        if x.shape[1] == 6 and latent is not None:
+            codes = codes + latent                                          # :56-58 residual step
+        else:
+            codes = codes + np.asarray(latent_avg).reshape(1, -1, codes.shape[2])     # :59-60 first step: latent_avg.repeat(N, 1, 1)
+        codes = codes.astype(np.float32)
+    eye = np.repeat(np.eye(3, dtype=np.float32)[None], x.shape[0], axis=0)          # :63-66
+    images = synthesis(gen_sd, sched, ws=codes, transform=eye)
+    if resize:
+        images = adaptive_avg_pool(images)
+    unaligned = None
+    if landmarks_transform is not None:                                     # :72-76
+        unaligned = synthesis(gen_sd, sched, ws=codes, transform=landmarks_transform.astype(np.float32))
+        if resize:
+            unaligned = adaptive_avg_pool(unaligned)
+    return images, unaligned, codes
+
+
+def get_average_image(enc_sd, gen_sd, sched, latent_avg):
+    """utils/inference_utils.py:59-64: the image of latent_avg repeated over the 16 styles, pooled (resize defaults to True)."""
+    x = np.repeat(latent_avg.reshape(1, -1), 16, axis=0)[None]
+    return psp_forward(enc_sd, gen_sd, sched, x, input_code=True)[0][0]
+
+
+def run_on_batch(enc_sd, gen_sd, sched, inputs, latent_avg, avg_image, n_iters, landmarks_transform=None, resize_outputs=False):
+    """utils/inference_utils.py:67-111.  Returns (per-step output images [steps][N,3,H,W], per-step latents [steps][N,16,512],
+    the ALIGNED image of the last step).  With transforms the reference's last entry is the unaligned image (:96-100); every
+    other quantity is the same with and without them, so one call pins both forms."""
+    y_hat, latent = None, None
+    step_images, step_latents = [], []
+    for it in range(n_iters):
+        second = np.repeat(avg_image[None], inputs.shape[0], axis=0) if it == 0 else y_hat          # :76-80
+        x_input = np.concatenate([inputs, second], axis=1).astype(np.float32)
+        aligned, unaligned, latent = psp_forward(enc_sd, gen_sd, sched, x_input, latent=latent, latent_avg=latent_avg,
+                                                 resize=resize_outputs, landmarks_transform=landmarks_transform)
+        # :92-100: aligned output, except that the LAST step returns the unaligned one when transforms are given
+        y_hat = unaligned if (landmarks_transform is not None and it == n_iters - 1) else aligned
+        step_images.append(y_hat)
+        step_latents.append(latent)
+        y_hat = adaptive_avg_pool(y_hat)                                     # :108 face_pool before the next step
+    return step_images, step_latents, aligned
+
+
 # ----------------------------------------------------------------------------
 # Callers of the synthesis path (SURVEY 8f): field-of-view expansion, video post-processing, StyleSpace edit sweep.
 # Restated from the reference text; these modules cannot be imported here (imageio / clip / pyrallis are absent),

@@ -116,3 +116,57 @@ class bottleneck_IR(_ResidualUnit):  # noqa: N801  (reference class name)
 
 class bottleneck_IR_SE(_ResidualUnit):  # noqa: N801  (reference class name)
     use_se = True
+
+
+class BasicBlock(Module):
+    """ResNet18/34 residual block with torchvision's module names (`conv1 bn1 relu conv2 bn2 downsample`), so the `body.*` keys
+    of a ReStyle ResNetBackboneEncoder checkpoint (reference restyle_psp_encoders.py:65-77 flattens resnet34's layer1..4)
+    load: y = relu(bn2(conv2(relu(bn1(conv1(x))))) + (downsample(x) | x)); conv1 carries the stride."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, (3, 3), stride, 1, bias=False)
+        self.bn1 = BatchNorm2d(planes)
+        self.relu = ReLU(inplace=True)
+        self.conv2 = Conv2d(planes, planes, (3, 3), 1, 1, bias=False)
+        self.bn2 = BatchNorm2d(planes)
+        self.downsample = None
+        if stride != 1 or inplanes != planes:
+            self.downsample = Sequential(Conv2d(inplanes, planes, (1, 1), stride, bias=False), BatchNorm2d(planes))
+        self.stride = stride
+        self._packed = None
+
+    def forward(self, x):
+        out = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        return self.relu(out + (x if self.downsample is None else self.downsample(x)))
+
+    def _pack(self):
+        from torch_utils.ops.plain_conv import ACT_LRELU, ACT_NONE, PackedConv, bn_affine
+        a1, b1 = bn_affine(self.bn1)
+        a2, b2 = bn_affine(self.bn2)
+        zero = torch.zeros([1], device=self.conv1.weight.device)            # ReLU = leaky ReLU with slope 0 in the epilogue
+        pk = dict(conv1=PackedConv(self.conv1.weight, out_scale=a1, bias=b1, act=ACT_LRELU, slope=zero, stride=self.stride, padding=1),
+                  conv2=PackedConv(self.conv2.weight, out_scale=a2, bias=b2, act=ACT_NONE, stride=1, padding=1))
+        if self.downsample is not None:
+            a, b = bn_affine(self.downsample[1])
+            pk['shortcut'] = PackedConv(self.downsample[0].weight, out_scale=a, bias=b, act=ACT_NONE, stride=self.stride, padding=0)
+        self._packed = pk
+
+    def forward_hip(self, x):
+        if self._packed is None:
+            self._pack()
+        pk = self._packed
+        res = pk['conv2'](pk['conv1'](x))
+        return torch.relu_(res.add_(pk['shortcut'](x) if 'shortcut' in pk else x))
+
+
+def resnet34_blocks():
+    """The 16 BasicBlocks of torchvision.models.resnet34's layer1..layer4 in order (3, 4, 6, 3 blocks of 64, 128, 256, 512
+    channels; the first block of layers 2..4 has stride 2 and a 1x1 projection shortcut)."""
+    blocks, inplanes = [], 64
+    for planes, count, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)):
+        for i in range(count):
+            blocks.append(BasicBlock(inplanes, planes, stride if i == 0 else 1))
+            inplanes = planes
+    return blocks

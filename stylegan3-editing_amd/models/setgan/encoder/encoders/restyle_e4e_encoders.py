@@ -2,15 +2,13 @@
 
 Same IR-SE50 trunk and GradualStyleBlock heads as the pSp backbone; the heads are combined as one base code plus
 per-style deltas: w[:, i] = w0 + delta_i for 1 <= i <= progressive_stage (:79-89).  Inherits the fused eval-mode HIP
-forward of `BackboneEncoder`.  The ResNet34 variant needs torchvision's pretrained weights and is unavailable offline.
+forward of `BackboneEncoder`.  `ResNetProgressiveBackboneEncoder` (:91-140) is the same combination on the ResNet34 trunk.
 Note: the reference constructor takes `input_nc` as its 4th positional argument while the e4e wrapper passes the options
 object there; both forms are accepted here.
 """
 from enum import Enum
 
-from torch.nn import Module
-
-from models.setgan.encoder.encoders.restyle_psp_encoders import BackboneEncoder
+from models.setgan.encoder.encoders.restyle_psp_encoders import BackboneEncoder, ResNetBackboneEncoder
 
 
 class ProgressiveStage(Enum):
@@ -38,11 +36,9 @@ class _NC:
         self.input_nc = input_nc
 
 
-class ProgressiveBackboneEncoder(BackboneEncoder):
-    def __init__(self, num_layers, mode='ir', n_styles=16, input_nc=3):
-        opts = input_nc if hasattr(input_nc, 'input_nc') else _NC(int(input_nc))
-        super().__init__(num_layers, mode, n_styles, opts)
-        self.progressive_stage = 99
+class _Progressive:
+    """w[:, 0] = w0, w[:, i] = w0 + delta_i for 1 <= i <= progressive_stage (reference :79-89, :128-140)."""
+    progressive_stage = 99
 
     def get_deltas_starting_dimensions(self):
         return list(range(self.style_count))
@@ -59,8 +55,15 @@ class ProgressiveBackboneEncoder(BackboneEncoder):
         return w
 
 
-class ResNetProgressiveBackboneEncoder(Module):
+class ProgressiveBackboneEncoder(_Progressive, BackboneEncoder):
+    def __init__(self, num_layers, mode='ir', n_styles=16, input_nc=3):
+        opts = input_nc if hasattr(input_nc, 'input_nc') else _NC(int(input_nc))
+        BackboneEncoder.__init__(self, num_layers, mode, n_styles, opts)
+        self.progressive_stage = 99
+
+
+class ResNetProgressiveBackboneEncoder(_Progressive, ResNetBackboneEncoder):
     def __init__(self, n_styles=16, input_nc=3):
-        super().__init__()
-        raise RuntimeError('ResNetProgressiveBackboneEncoder needs torchvision.models.resnet34(pretrained=True) (reference '
-                           'restyle_e4e_encoders.py:104); torchvision and its weights are not available in this offline build')
+        opts = input_nc if hasattr(input_nc, 'input_nc') else _NC(int(input_nc))
+        ResNetBackboneEncoder.__init__(self, n_styles, opts)
+        self.progressive_stage = 99

@@ -4,14 +4,17 @@
 then `n_styles` GradualStyleBlock heads, stacked to [N, n_styles, 512].  Module names and therefore state_dict keys are
 the reference's.  In eval mode on a GPU the backbone runs on libsg3hip's matrix-core convolution with BatchNorm / PReLU
 fused, and the style heads (tiny maps, weight-bandwidth bound) as batched GEMMs over all heads on unfolded patches.
-`ResNetBackboneEncoder` (:53-97) needs torchvision's pretrained ResNet34, which is neither installed nor downloadable
-here; constructing it raises with that explanation.
+`ResNetBackboneEncoder` (:53-97): the same heads on a ResNet34 trunk (7x7 stride-2 stem without max-pool, then torchvision's
+layer1..layer4 BasicBlocks flattened into `body`, so the keys are `conv1 / bn1 / relu / body.{0..15}.{conv1,bn1,conv2,bn2,
+downsample.{0,1}} / styles.*`).  The reference seeds the trunk from `torchvision.models.resnet34(pretrained=True)`, which is
+neither installed nor downloadable here: the trunk is built from this repository's own `BasicBlock` with default
+initialisation and takes its weights from the encoder checkpoint (which holds all of them).
 """
 import torch
 from torch import nn
 from torch.nn import BatchNorm2d, Conv2d, Module, PReLU, Sequential
 
-from models.setgan.encoder.encoders.helpers import bottleneck_IR, bottleneck_IR_SE, get_blocks
+from models.setgan.encoder.encoders.helpers import bottleneck_IR, bottleneck_IR_SE, get_blocks, resnet34_blocks
 from models.setgan.encoder.encoders.map2style import GradualStyleBlock
 
 
@@ -26,18 +29,24 @@ def _patches_3x3_s2(h):
     return torch.stack(taps, dim=2).reshape(b, c * 9, oh * ow)
 
 
-class BackboneEncoder(Module):
-    def __init__(self, num_layers, mode='ir', n_styles=18, opts=None):
-        super().__init__()
-        assert num_layers in [50, 100, 152], 'num_layers should be 50,100, or 152'
-        assert mode in ['ir', 'ir_se'], 'mode should be ir or ir_se'
-        unit = bottleneck_IR if mode == 'ir' else bottleneck_IR_SE
-        input_nc = getattr(opts, 'input_nc', 6) if opts is not None else 6
-        self.input_layer = Sequential(Conv2d(input_nc, 64, (3, 3), 1, 1, bias=False), BatchNorm2d(64), PReLU(64))
-        self.body = Sequential(*[unit(b.in_channel, b.depth, b.stride) for stage in get_blocks(num_layers) for b in stage])
+class _StyleHeadEncoder(Module):
+    """What the two backbones share: `n_styles` GradualStyleBlock heads on the trunk's [N,512,16,16] map, the packed-weight
+    cache of the fused GPU path, and the dispatch between that path and the plain PyTorch definition.  Subclasses provide the
+    trunk: `_trunk_torch(x)`, `_pack_trunk(pk)`, `_trunk_hip(pk, x)`."""
+
+    def _init_heads(self, n_styles):
         self.styles = nn.ModuleList([GradualStyleBlock(512, 512, 16) for _ in range(n_styles)])
         self.style_count = n_styles
         self._packed = None
+        self._packed_key = None
+        # a parent's load_state_dict (pSp / e4e: net.load_state_dict(ckpt)) recurses through _load_from_state_dict and never
+        # calls this module's load_state_dict override; the post hook runs for every module of the tree that is loaded
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
+
+    def _weights_key(self):
+        """(data_ptr, _version) of every parameter and buffer the packed / folded copies are derived from: in-place edits
+        (optimizer.step, EMA copy_, new BatchNorm statistics) and re-bound tensors change it."""
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 
     def _combine(self, per_style):
         """[style_count x [N,512]] -> [N, style_count, 512] (the e4e variant overrides this with w0 + deltas)."""
@@ -45,13 +54,14 @@ class BackboneEncoder(Module):
 
     # plain PyTorch definition (CPU, training)
     def _forward_torch(self, x):
-        x = self.body(self.input_layer(x))
+        x = self._trunk_torch(x)
         return self._combine([style(x) for style in self.styles])
 
     def invalidate_packed(self):
         """Drop the packed / folded weights (call after changing parameters or BatchNorm statistics)."""
         self._packed = None
-        for m in self.body:
+        self._packed_key = None
+        for m in getattr(self, 'body', ()):
             m._packed = None
 
     def train(self, mode=True):
@@ -67,10 +77,8 @@ class BackboneEncoder(Module):
         return super()._apply(fn, *args, **kwargs)
 
     def _pack(self):
-        from torch_utils.ops.plain_conv import ACT_PRELU, PackedConv, bn_affine
-        conv, bn, prelu = self.input_layer[0], self.input_layer[1], self.input_layer[2]
-        a, b = bn_affine(bn)
-        pk = dict(stem=PackedConv(conv.weight, out_scale=a, bias=b, act=ACT_PRELU, slope=prelu.weight, stride=1, padding=1))
+        pk = {}
+        self._pack_trunk(pk)
         # Head convolutions.  Every style block starts from the same [N,512,16,16] map and halves it to 8x8, 4x4, 2x2,
         # 1x1: far too few pixels for an implicit-GEMM tile, and what bounds them is reading the weights (16 heads x 4
         # levels x 9.4 MB).  They run as plain GEMMs on patches taken with unfold: the first level of all heads as ONE
@@ -102,12 +110,14 @@ class BackboneEncoder(Module):
         return out
 
     def _forward_kernels(self, x):
+        key = self._weights_key()
+        if self._packed is not None and key != self._packed_key:
+            self.invalidate_packed()          # the source tensors changed behind the hooks (in-place update): re-pack
         if self._packed is None:
             self._pack()
+            self._packed_key = key
         pk = self._packed
-        x = pk['stem'](x.float())
-        for unit in self.body:
-            x = unit.forward_hip(x)
+        x = self._trunk_hip(pk, x.float())
         n, heads, c = int(x.shape[0]), len(self.styles), self.styles[0].out_c
         side = (int(x.shape[2]) + 1) // 2
         cols = _patches_3x3_s2(x)                                                                     # [N, C*9, side^2]
@@ -129,8 +139,60 @@ class BackboneEncoder(Module):
         return self._forward_torch(x)
 
 
-class ResNetBackboneEncoder(Module):
+class BackboneEncoder(_StyleHeadEncoder):
+    def __init__(self, num_layers, mode='ir', n_styles=18, opts=None):
+        super().__init__()
+        assert num_layers in [50, 100, 152], 'num_layers should be 50,100, or 152'
+        assert mode in ['ir', 'ir_se'], 'mode should be ir or ir_se'
+        unit = bottleneck_IR if mode == 'ir' else bottleneck_IR_SE
+        input_nc = getattr(opts, 'input_nc', 6) if opts is not None else 6
+        self.input_layer = Sequential(Conv2d(input_nc, 64, (3, 3), 1, 1, bias=False), BatchNorm2d(64), PReLU(64))
+        self.body = Sequential(*[unit(b.in_channel, b.depth, b.stride) for stage in get_blocks(num_layers) for b in stage])
+        self._init_heads(n_styles)
+
+    def _trunk_torch(self, x):
+        return self.body(self.input_layer(x))
+
+    def _pack_trunk(self, pk):
+        from torch_utils.ops.plain_conv import ACT_PRELU, PackedConv, bn_affine
+        conv, bn, prelu = self.input_layer[0], self.input_layer[1], self.input_layer[2]
+        a, b = bn_affine(bn)
+        pk['stem'] = PackedConv(conv.weight, out_scale=a, bias=b, act=ACT_PRELU, slope=prelu.weight, stride=1, padding=1)
+
+    def _trunk_hip(self, pk, x):
+        x = pk['stem'](x)
+        for unit in self.body:
+            x = unit.forward_hip(x)
+        return x
+
+
+class ResNetBackboneEncoder(_StyleHeadEncoder):
+    """ResNet34 trunk (reference :53-97): conv7x7 s2 (input_nc -> 64) + BN + PReLU at 128^2 (no max-pool), then the 3 + 4 + 6 + 3
+    BasicBlocks of torchvision's resnet34 as one flat `body`, down to [N,512,16,16]."""
+
     def __init__(self, n_styles=18, opts=None):
         super().__init__()
-        raise RuntimeError('ResNetBackboneEncoder needs torchvision.models.resnet34(pretrained=True) (reference '
-                           'restyle_psp_encoders.py:65); torchvision and its weights are not available in this offline build')
+        input_nc = getattr(opts, 'input_nc', 6) if opts is not None else 6
+        self.conv1 = Conv2d(input_nc, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = BatchNorm2d(64)
+        self.relu = PReLU(64)
+        self.body = Sequential(*resnet34_blocks())
+        self._init_heads(n_styles)
+
+    def _trunk_torch(self, x):
+        return self.body(self.relu(self.bn1(self.conv1(x))))
+
+    def _pack_trunk(self, pk):
+        from torch_utils.ops.plain_conv import bn_affine
+        a, b = bn_affine(self.bn1)
+        # the 7x7 stride-2 stem (0.6 % of the trunk's FLOPs, 6 input channels) is the one convolution left to the library: the
+        # matrix-core kernel takes 1x1 / 3x3 windows.  BatchNorm is folded into its weights, the PReLU follows as one op
+        pk['stem_w'] = (self.conv1.weight.detach() * a.view(-1, 1, 1, 1)).contiguous()
+        pk['stem_b'] = b.contiguous()
+
+    def _trunk_hip(self, pk, x):
+        x = torch.nn.functional.prelu(torch.nn.functional.conv2d(x, pk['stem_w'], pk['stem_b'], stride=2, padding=3), self.relu.weight)
+        for block in self.body:
+            x = block.forward_hip(x)
+        return x
+

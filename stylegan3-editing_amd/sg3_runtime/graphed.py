@@ -5,6 +5,15 @@ ops); at batch 8 the kernels take ~24 ms and the launch gaps ~3 ms.  Capturing t
 (torch.cuda.CUDAGraph: our ctypes launches go to torch's current stream, which is the capture stream) and replaying
 it removes the gaps and all Python overhead.  The graph owns static input/output buffers: `ws` (or the StyleSpace dict)
 is copied in, the image comes out of a static tensor that is overwritten by the next replay.
+
+What a captured graph bakes in, and how a replay stays valid:
+  * device pointers of every tensor it reads.  `synthesis.input.transform` is REBOUND by the callers (pSp.forward,
+    PTI, the FOV expander assign a fresh tensor per call), so the graph owns a static [batch,3,3] transform buffer, installs
+    it on the module for the capture and, on every replay, copies whatever transform the module (or the `transform=`
+    argument) currently holds into it and re-installs it;
+  * host-side values derived from parameters (activation bounds inside the convolution launch parameters, the
+    magnitude_ema gains of eager-mode prep).  Parameters and buffers are fingerprinted at capture (data_ptr, _version); a
+    replay after any of them changed raises instead of returning an image of the old weights: re-capture after tuning.
 """
 import torch
 
@@ -24,6 +33,9 @@ class GraphedSynthesis:
             self.static_ws = None
         else:
             self.static_ws = torch.zeros([batch, generator.num_ws, generator.w_dim], device=dev)
+        self.batch = int(batch)
+        self.static_transform = torch.eye(3, device=dev).repeat(self.batch, 1, 1)
+        self._install_transform(generator.synthesis.input.transform)
         # warm up on a side stream (lazy inits, bound caches, allocator), then capture
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -37,14 +49,33 @@ class GraphedSynthesis:
         # events) may keep calling into the runtime while this thread captures
         with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.static_out = self._eager()
+        self._fingerprint = self._weights_fingerprint()
+
+    def _install_transform(self, t):
+        """Copy `t` ([3,3] or [batch,3,3]) into the graph's transform buffer and make that buffer the module's transform."""
+        if t is not self.static_transform:
+            t = torch.as_tensor(t, device=self.device, dtype=torch.float32)
+            if t.dim() == 3 and t.shape[0] not in (1, self.batch):
+                raise ValueError(f'transform batch {t.shape[0]} does not match the captured batch {self.batch}')
+            self.static_transform.copy_(t.expand(self.batch, 3, 3) if t.dim() == 3 else t.unsqueeze(0).expand(self.batch, 3, 3))
+        self.G.synthesis.input.transform = self.static_transform
+
+    def _weights_fingerprint(self):
+        inp = self.G.synthesis.input
+        return tuple((t.data_ptr(), t._version) for t in list(self.G.synthesis.parameters()) + list(self.G.synthesis.buffers())
+                     if t is not self.static_transform and t is not inp.transform)
 
     def _eager(self):
         if self.use_s:
             return self.G.synthesis(None, all_s=self.static_s, **self.kwargs)
         return self.G.synthesis(self.static_ws, **self.kwargs)
 
-    def __call__(self, ws=None, all_s=None):
-        """Copy the inputs into the graph's static buffers, replay, return the static output tensor."""
+    def __call__(self, ws=None, all_s=None, transform=None):
+        """Copy the inputs (and the current user transform) into the graph's static buffers, replay, return the static output."""
+        if self._weights_fingerprint() != self._fingerprint:
+            raise RuntimeError('GraphedSynthesis: generator parameters / buffers changed since capture (the graph holds their old '
+                               'pointers and values derived from them); build a new GraphedSynthesis')
+        self._install_transform(self.G.synthesis.input.transform if transform is None else transform)
         if self.use_s:
             for k, v in all_s.items():
                 self.static_s[k].copy_(v, non_blocking=True)

@@ -77,14 +77,18 @@ class _ConvNd(torch.autograd.Function):
                 op = [x.shape[i + 2] - ((dy.shape[i + 2] - 1) * stride[i] - 2 * padding[i] + dilation[i] * (w.shape[i + 2] - 1) + 1) for i in range(2)]
                 dx = conv_transpose2d(dy, w, None, stride, padding, tuple(op), groups, dilation)
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
+            # under create_graph (this backward runs with grad mode on) the weight gradient must stay differentiable w.r.t. BOTH
+            # dy and x: the reference's Conv2dGradWeight.backward returns grad_input as well (conv2d_gradfix.py:175-190), which an
+            # R1 / path-length penalty on the weights needs
+            higher_order = torch.is_grad_enabled()
             with torch.enable_grad():
-                xd = x.detach().requires_grad_(False)
+                xd = x if (higher_order and x.requires_grad) else x.detach()
                 wd = w.detach().requires_grad_(True)
                 if transpose:
                     y = torch.nn.functional.conv_transpose2d(xd, wd, None, stride, padding, output_padding, groups, dilation)
                 else:
                     y = torch.nn.functional.conv2d(xd, wd, None, stride, padding, dilation, groups)
-                dw, = torch.autograd.grad(y, wd, dy, create_graph=torch.is_grad_enabled() and dy.requires_grad)
+                dw, = torch.autograd.grad(y, wd, dy, create_graph=higher_order and (dy.requires_grad or xd.requires_grad))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum([0, 2, 3])
         return dx, dw, db, None, None, None, None, None, None

@@ -51,7 +51,11 @@ def build_oracle_generator(cfg, seed=0):
     from oracle import oracle as O
     from synth_weights import CONFIGS, synth_state_dict
     sched = O.layer_schedule(**CONFIGS[cfg])
-    man = {k: v for k, v in manifest()[cfg].items()}
+    if cfg in manifest():
+        man = {k: v for k, v in manifest()[cfg].items()}
+    else:       # configurations without a reference-dumped manifest (the mini decoders): shapes of the product's state_dict
+        from models.stylegan3.networks_stylegan3 import Generator
+        man = {k: list(v.shape) for k, v in Generator(**CONFIGS[cfg]).state_dict().items() if not k.endswith('_filter')}
     sd = synth_state_dict(man, seed=seed, input_bandwidth=sched['input']['bandwidth'])
     sd.update(O.filter_taps_for(sched))
     return sd, sched
@@ -59,3 +63,21 @@ def build_oracle_generator(cfg, seed=0):
 
 def maxabs(a, b):
     return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
+
+
+def build_restyle_pair(cfg, device='cpu', encoder_type='BackboneEncoder', n_iters=5):
+    """(product pSp net on `device`, opts, oracle encoder state dict, oracle generator state dict, schedule): the same
+    seeded synthetic IR-SE50 encoder and decoder on both sides."""
+    import types
+    import torch
+    from models.setgan.encoder.psp3 import pSp
+    from synth_weights import synth_encoder_state_dict
+    G = build_product_generator(cfg)
+    opts = types.SimpleNamespace(encoder_type=encoder_type, input_nc=6, checkpoint_path=None, n_iters_per_batch=n_iters, resize_outputs=False)
+    net = pSp(opts, decoder=G)
+    man = {k: list(v.shape) for k, v in net.encoder.state_dict().items()}
+    enc_sd = {k: np.asarray(v) for k, v in synth_encoder_state_dict(man, seed=0).items()}
+    net.encoder.load_state_dict({k: torch.from_numpy(v) for k, v in enc_sd.items()})
+    net = net.eval().requires_grad_(False).to(device)
+    gen_sd, sched = build_oracle_generator(cfg)
+    return net, opts, enc_sd, gen_sd, sched

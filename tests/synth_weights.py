@@ -32,6 +32,11 @@ CONFIGS = {
                   channel_base=512, channel_max=12),
     'Rtiny': dict(z_dim=32, c_dim=0, w_dim=32, img_resolution=64, img_channels=3,
                   channel_base=1024, channel_max=16, conv_kernel=1, use_radial_filters=True),
+    # the tiny decoders with the 512-wide latent the ReStyle encoder emits (ReStyle loop tests)
+    'Tmini': dict(z_dim=512, c_dim=0, w_dim=512, img_resolution=64, img_channels=3,
+                  channel_base=512, channel_max=12),
+    'Rmini': dict(z_dim=512, c_dim=0, w_dim=512, img_resolution=64, img_channels=3,
+                  channel_base=1024, channel_max=16, conv_kernel=1, use_radial_filters=True),
 }
 
 
@@ -127,6 +132,8 @@ def synth_encoder_tensor(key, shape, seed=0):
         return (0.05 * r.randn(*shape)).astype(np.float32)
     # 1-D: BatchNorm weight / bias or PReLU slope; told apart by the module position in the reference layout
     parts = key.split('.')
+    if key == 'relu.weight':                              # PReLU of the ResNet34 stem
+        return r.uniform(0.1, 0.4, size=shape).astype(np.float32)
     if leaf == 'weight' and (parts[-2] == '2' and parts[0] in ('input_layer',) or (len(parts) >= 3 and parts[-3] == 'res_layer' and parts[-2] == '2')):
         return r.uniform(0.1, 0.4, size=shape).astype(np.float32)        # PReLU
     if leaf == 'weight':

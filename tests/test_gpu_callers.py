@@ -94,3 +94,21 @@ def test_batched_forms_equal_per_item_forms_full_size():
     # the left tile is the centre image shifted by 64 px: where both exist they agree (interior, away from the margin)
     centre = big[:, :, 16:16 + 512, 64:64 + 512]
     assert maxabs(left[:, :, 100:400, 64 + 100:64 + 300].cpu().numpy(), centre[:, :, 100:400, 100:300].cpu().numpy()) <= 5e-3
+
+
+def test_styleclip_sweep_batch32_equals_single_renders():
+    """BASELINE configs[4] shape: AFHQ-512 config-R, the 5 x 11 edit sweep rendered in StyleSpace batches of 32 (the reference
+    renders the 55 edits one by one, edit.py:136-160): every image of the batched sweep equals its batch-1 render."""
+    from editing.styleclip_global_directions.edit import render_sweep
+    G = build_product_generator('R512', device=DEV)
+    w = torch.from_numpy(synth_ws(1, G.num_ws, G.w_dim, seed=8)).to(DEV)
+    with torch.no_grad():
+        base = G.synthesis.W2S(w)
+        r = np.random.RandomState(13)
+        sweep = {c: v.repeat(55, 1) + torch.from_numpy((0.3 * r.randn(55, 1) * (r.rand(1, v.shape[1]) < 0.05)).astype(np.float32)).to(DEV) for c, v in base.items()}
+        batched = render_sweep(G, sweep, max_batch=32, force_fp32=True)
+        assert tuple(batched.shape) == (55, 3, 512, 512)
+        for i in (0, 31, 32, 54):          # both batches (32 + 23), first and last of each
+            single = G.synthesis(None, all_s={c: v[i:i + 1] for c, v in sweep.items()}, noise_mode='const', force_fp32=True)
+            assert maxabs(batched[i:i + 1].cpu().numpy(), single.cpu().numpy()) <= 1e-5, i
+        assert maxabs(batched[0].cpu().numpy(), batched[54].cpu().numpy()) > 1e-3

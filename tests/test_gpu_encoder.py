@@ -109,3 +109,31 @@ def test_split_precision_range_guard():
         finally:
             plain_conv.precision = saved
     assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
+def test_packed_weights_follow_parent_load_and_inplace_updates():
+    """`net.load_state_dict(ckpt)` on the PARENT (pSp) recurses without calling the encoder's own load_state_dict, and
+    in-place edits (optimizer.step / EMA copy_) pass no hook at all: the packed copies must follow both."""
+    import types
+    from models.setgan.encoder.psp3 import pSp
+    from helpers import build_product_generator
+    from synth_weights import synth_encoder_state_dict
+    G = build_product_generator('Ttiny')
+    opts = types.SimpleNamespace(encoder_type='BackboneEncoder', input_nc=6, checkpoint_path=None, n_iters_per_batch=1, resize_outputs=False)
+    net = pSp(opts, decoder=G)
+    man = {k: list(v.shape) for k, v in net.encoder.state_dict().items()}
+    net.encoder.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth_encoder_state_dict(man, seed=0).items()})
+    net = net.eval().requires_grad_(False).to(DEV)
+    x = torch.from_numpy(_input()).to(DEV)
+    with torch.no_grad():
+        first = net.encoder(x).clone()
+        other = {'encoder.' + k: torch.from_numpy(np.asarray(v)) for k, v in synth_encoder_state_dict(man, seed=3).items()}
+        net.load_state_dict(other, strict=False)                       # parent-level load
+        second = net.encoder(x).clone()
+        assert maxabs(second.cpu().numpy(), net.encoder._forward_torch(x).cpu().numpy()) <= 2e-3
+        assert maxabs(second.cpu().numpy(), first.cpu().numpy()) > 1e-2
+        net.encoder.body[3].res_layer[4].running_mean.add_(0.3)        # in-place statistics update, no hook fires
+        net.encoder.styles[2].linear.bias.mul_(2.0)
+        third = net.encoder(x)
+        assert maxabs(third.cpu().numpy(), net.encoder._forward_torch(x).cpu().numpy()) <= 2e-3
+        assert maxabs(third.cpu().numpy(), second.cpu().numpy()) > 1e-3

@@ -204,3 +204,50 @@ def test_torgb_epilogue_fused_and_refused():
         w3 = torch.randn([8, 32, 3, 3], device=DEV, generator=g)
         with pytest.raises(RuntimeError, match='ToRGB'):
             mc.modulated_conv2d(x, w3, s, padding=2, epilogue=(torch.zeros(8, device=DEV), 40.0, 1.0))
+
+
+def test_t1024_batch8_headline_workload():
+    """BASELINE configs[1] exactly as bench.py runs it (batch 8, force_fp32): sample 0 against the reference's golden samples /
+    statistics, sample 7 against its own batch-1 forward, eagerly and through the captured hipGraph."""
+    from sg3_runtime import GraphedSynthesis
+    g = golden('net_t1024_stats')
+    G = build_product_generator('T1024', device=DEV)
+    ws_np = np.concatenate([synth_ws(1, G.num_ws, G.w_dim, seed=1)] + [synth_ws(1, G.num_ws, G.w_dim, seed=20 + i) for i in range(7)])
+    ws = T(ws_np)
+    with torch.no_grad():
+        img = G.synthesis(ws, noise_mode='const', force_fp32=True)
+        one = G.synthesis(ws[7:8], noise_mode='const', force_fp32=True)
+    assert tuple(img.shape) == (8, 3, 1024, 1024)
+    assert maxabs(img[:1, :, ::16, ::16].cpu().numpy(), g['T1024/img_sub']) <= 1e-4
+    assert maxabs(img[:1, :, [0, 511, 1023], :].cpu().numpy(), g['T1024/img_rows']) <= 1e-4
+    assert abs(img[:1].mean().item() - g['T1024/img_stats'][0]) <= 1e-5
+    assert maxabs(img[7:8].cpu().numpy(), one.cpu().numpy()) <= 1e-5
+    replay = GraphedSynthesis(G, 8)(ws)
+    assert maxabs(replay.cpu().numpy(), img.cpu().numpy()) <= 1e-6
+
+
+def test_graph_replay_follows_transform_rebinding_and_refuses_stale_weights():
+    """callers rebind `synthesis.input.transform` to fresh tensors (pSp.forward, PTI); a replay must render under the
+    CURRENT transform, not read the freed tensor captured earlier, and must refuse to replay after the weights changed."""
+    import gc
+    from sg3_runtime import GraphedSynthesis
+    G = build_product_generator('Ttiny', device=DEV)
+    ws = T(synth_ws(2, G.num_ws, G.w_dim, seed=1))
+    graphed = GraphedSynthesis(G, 2)
+    for tr in (make_user_transform(), np.stack([make_user_transform((0.1, -0.05), 15.0), make_user_transform((-0.2, 0.07), -30.0)]), np.eye(3, dtype=np.float32)):
+        G.synthesis.input.transform = T(tr)                    # a fresh tensor, as the callers do
+        junk = [torch.randn(3, 3, device=DEV) for _ in range(64)]     # recycle the allocator blocks the old transforms lived in
+        del junk; gc.collect()
+        got = graphed(ws).clone()
+        G.synthesis.input.transform = T(tr)
+        with torch.no_grad():
+            want = G.synthesis(ws, noise_mode='const', force_fp32=True)
+        assert maxabs(got.cpu().numpy(), want.cpu().numpy()) <= 1e-6
+    got = graphed(ws, transform=T(make_user_transform((0.3, 0.1), 45.0))).clone()
+    G.synthesis.input.transform = T(make_user_transform((0.3, 0.1), 45.0))
+    with torch.no_grad():
+        assert maxabs(got.cpu().numpy(), G.synthesis(ws, noise_mode='const', force_fp32=True).cpu().numpy()) <= 1e-6
+    with torch.no_grad():
+        G.synthesis.L3_36_12.bias.add_(0.5)                    # tuning step
+    with pytest.raises(RuntimeError, match='changed since capture'):
+        graphed(ws)

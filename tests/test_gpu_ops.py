@@ -230,6 +230,41 @@ def test_filtered_lrelu_radial_training_kernels(shape, up, taps, pad, clamp, mir
         assert maxabs(b.grad.cpu().numpy(), br.grad.numpy()) <= 2e-3 * max(1.0, float(br.grad.abs().max()))
 
 
+@pytest.mark.parametrize('shape,up,taps,pad,radial', [
+    ((1, 2, 150, 150), 2, 12, [9, 8, 9, 8], False),           # T up-2 (adjoint: up 2 / down 2)
+    ((2, 2, 86, 86), 4, 24, [-6, -9, -6, -9], False),          # T up-4 (adjoint: up 2 / down 4)
+    ((1, 2, 84, 150), 2, 12, [11, 10, 11, 10], True),          # R up-2, 12x12 down filter (adjoint: 12x12 up filter)
+])
+def test_filtered_lrelu_fused_sign_kernels_fp16_io(shape, up, taps, pad, radial):
+    """fp16 activations through the sign-writing forward and the sign-reading adjoint (the reference's default mixed-precision
+    PTI, filtered_lrelu.py:198-269 with x.dtype == float16): against the fp32 CPU formulation fed with the same fp16-rounded
+    inputs; tolerance = one fp16 rounding of the result (values are O(1..4))."""
+    from oracle import oracle as O
+    from torch_utils.ops import filtered_lrelu as fl
+    fl._init()
+    fu = O.design_lowpass_filter(taps, 4.0, 8.0, 64.0 * up / 2)
+    fd = O.design_lowpass_filter(12, 5.0, 9.0, 64.0, radial=radial)
+    xh = torch.from_numpy(rand(3, *shape)).half()
+    bh = torch.from_numpy(rand(4, shape[1])).half()
+    kw = dict(up=up, down=2, padding=pad, gain=float(np.sqrt(2)), slope=0.2, clamp=256, flip_filter=False)
+    y0, so, rc = fl._plugin.filtered_lrelu(xh.to(DEV), T(fu), T(fd), bh.to(DEV), torch.empty(0), up, 2, *pad, 0, 0, kw['gain'], 0.2, 256.0, False, True)
+    assert rc == 0 and y0.dtype == torch.float16 and so.dtype == torch.uint8 and so.numel() > 0
+    xr = xh.float().requires_grad_(True); br = bh.float().requires_grad_(True)
+    yr = fl.filtered_lrelu(xr, torch.from_numpy(fu), torch.from_numpy(fd), br, impl='ref', **kw)
+    gy = torch.from_numpy(rand(5, *yr.shape)).half()
+    (yr * gy.float()).sum().backward()
+    x = xh.to(DEV).requires_grad_(True); b = bh.to(DEV).requires_grad_(True)
+    y = fl.filtered_lrelu(x, T(fu), T(fd), b, **kw)
+    assert y.dtype == torch.float16
+    (y.float() * gy.to(DEV).float()).sum().backward()
+    scale = max(1.0, float(yr.abs().max()))
+    assert maxabs(y0.float().cpu().numpy(), yr.detach().numpy()) <= 1e-3 * scale
+    assert maxabs(y.detach().float().cpu().numpy(), yr.detach().numpy()) <= 1e-3 * scale
+    assert x.grad.dtype == torch.float16
+    assert maxabs(x.grad.float().cpu().numpy(), xr.grad.numpy()) <= 1e-3 * max(1.0, float(xr.grad.abs().max()))
+    assert maxabs(b.grad.float().cpu().numpy(), br.grad.numpy()) <= 4e-3 * max(1.0, float(br.grad.abs().max()))
+
+
 def test_filtered_lrelu_act_signs_roundtrip():
     """filtered_lrelu_act_: written signs reproduce the activation derivative when read back."""
     from torch_utils.ops import filtered_lrelu

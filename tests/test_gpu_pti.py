@@ -55,3 +55,88 @@ def test_video_pti_matches_reference():
         final = G.synthesis(torch.from_numpy(codes[:1]).to(DEV), noise_mode='const', force_fp32=True).cpu().numpy()
     assert maxabs(final, g['Ttiny/video/final']) <= 5e-4
     check_weights(G.state_dict()['synthesis.L0_36_12.weight'].cpu().numpy(), g['Ttiny/video/synthesis.L0_36_12.weight'], 3e-3, 4)
+
+
+def _layer_cases(cfg, names):
+    """(name, x side, up, padding, fu, fd) of the named layers of a full-size generator (filters as the product designs them:
+    pinned against the reference's taps in test_product_cpu / golden filters.npz)."""
+    from helpers import build_product_generator
+    G = build_product_generator(cfg)
+    out = []
+    for name in G.synthesis.layer_names:
+        if name.split('_')[0] in names:
+            L = getattr(G.synthesis, name)
+            out.append((name, int(L.in_size[0]) + L.conv_kernel - 1, L.up_factor, list(L.padding), L.up_filter.numpy(), L.down_filter.numpy()))
+    return out
+
+
+@pytest.mark.parametrize('cfg,names', [('T1024', ('L10', 'L11', 'L13')), ('R1024', ('L10', 'L11', 'L13'))])
+def test_pti_filter_kernels_at_1024_geometry(cfg, names):
+    """The 1024^2 sign-writing forward and sign-reading adjoint (the PTI path of BASELINE configs[3]) on a cropped plane set
+    (2 channels of the real layer geometry: the kernels treat planes independently): output, dx and db against autograd through
+    the reference formulation on the CPU (`impl='ref'`, reference filtered_lrelu.py:122-154)."""
+    from golden_cases import rand
+    from torch_utils.ops import filtered_lrelu as fl
+    for name, side, up, pad, fu, fd in _layer_cases(cfg, names):
+        xn, bn = rand(21, 1, 2, side, side), rand(22, 2)
+        kw = dict(up=up, down=2, padding=pad, gain=float(np.sqrt(2)), slope=0.2, clamp=256, flip_filter=False)
+        xr = torch.from_numpy(xn).requires_grad_(True); br = torch.from_numpy(bn).requires_grad_(True)
+        yr = fl.filtered_lrelu(xr, torch.from_numpy(fu), torch.from_numpy(fd), br, impl='ref', **kw)
+        gy = rand(23, *yr.shape)
+        loss_r = (yr * torch.from_numpy(gy)).sum()
+        loss_r.backward()
+        x = torch.from_numpy(xn).to(DEV).requires_grad_(True); b = torch.from_numpy(bn).to(DEV).requires_grad_(True)
+        y = fl.filtered_lrelu(x, torch.from_numpy(fu).to(DEV), torch.from_numpy(fd).to(DEV), b, **kw)
+        loss = (y * torch.from_numpy(gy).to(DEV)).sum()
+        loss.backward()
+        assert tuple(y.shape) == tuple(yr.shape), name
+        assert maxabs(y.detach().cpu().numpy(), yr.detach().numpy()) <= 2e-5, name
+        assert abs(loss.item() - loss_r.item()) <= 1e-4 * max(1.0, abs(loss_r.item())), name
+        assert maxabs(x.grad.cpu().numpy(), xr.grad.numpy()) <= 5e-5, name
+        assert maxabs(b.grad.cpu().numpy(), br.grad.numpy()) <= 1e-4 * max(1.0, float(br.grad.abs().max())), name
+
+
+@pytest.mark.parametrize('cfg', ['T1024', 'R1024'])
+def test_pti_step_at_full_size(cfg):
+    """One pivotal-tuning step at FFHQ-1024 on the HIP path: the sign-writing training forward reproduces the inference forward,
+    the loss gradient agrees with central differences of the loss along a random direction of the last layers' biases and
+    weights, and one Adam step lowers the loss."""
+    from helpers import build_product_generator
+    G = build_product_generator(cfg, device=DEV)
+    w = torch.from_numpy(synth_ws(1, G.num_ws, G.w_dim, seed=3)).to(DEV)
+    with torch.no_grad():
+        ref_img = G.synthesis(w, noise_mode='const', force_fp32=True)
+    target = (0.5 * ref_img + 0.1).detach()
+    G.requires_grad_(True)
+    params = list(G.synthesis.parameters())[3:]
+    out = G.synthesis(w, noise_mode='const', force_fp32=True)
+    assert maxabs(out.detach().cpu().numpy(), ref_img.cpu().numpy()) <= 2e-5          # training forward == inference forward
+    loss = torch.nn.functional.mse_loss(out, target)
+    grads = torch.autograd.grad(loss, params)
+    assert all(bool(torch.isfinite(g).all()) for g in grads)
+    # directional derivative along a random direction over the parameters of the last three layers
+    names = [n for n, _ in G.synthesis.named_parameters()][3:]
+    pick = [i for i, n in enumerate(names) if n.split('.')[0].split('_')[0] in ('L12', 'L13', 'L14')]
+    r = torch.Generator(device='cpu').manual_seed(5)
+    dirs = {i: torch.randn(params[i].shape, generator=r).to(DEV) for i in pick}
+    analytic = sum(float((grads[i].double() * dirs[i].double()).sum()) for i in pick)
+
+    def loss_at(eps):
+        with torch.no_grad():
+            for i in pick:
+                params[i].add_(dirs[i], alpha=eps)
+            val = torch.nn.functional.mse_loss(G.synthesis(w, noise_mode='const', force_fp32=True).double(), target.double()).item()
+            for i in pick:
+                params[i].sub_(dirs[i], alpha=eps)
+        return val
+    eps = 1e-3
+    numeric = (loss_at(eps) - loss_at(-eps)) / (2 * eps)
+    assert abs(numeric - analytic) <= 2e-2 * max(abs(analytic), 1e-6), (numeric, analytic)
+    opt = torch.optim.Adam(params, lr=3e-4)
+    opt.zero_grad()
+    for p_, g_ in zip(params, grads):
+        p_.grad = g_
+    opt.step()
+    with torch.no_grad():
+        after = torch.nn.functional.mse_loss(G.synthesis(w, noise_mode='const', force_fp32=True), target).item()
+    assert after < loss.item(), (after, loss.item())

@@ -1,0 +1,91 @@
+"""GPU: the ReStyle loop (BASELINE configs[2]) on the HIP path -- `pSp.forward`, `get_average_image`,
+`run_on_batch` with the IR-SE50 encoder -- against the oracle's restatement of reference models/setgan/encoder/psp3.py:45-84
+and utils/inference_utils.py:59-111, and at full size (R-1024 decoder, batch 16, 5 steps) through golden encoder codes and
+batch-independence.
+
+Tolerances: the loop feeds its own output back five times through a 50-layer encoder with random (untrained) weights, so a
+1e-7 difference in step k's image reaches the step k+1 latent amplified; latents are O(1..10).  Images: 1e-4 (the
+BASELINE bound).  Latents: 2e-4 * max|latent| per step."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_product_generator, build_restyle_pair, golden, maxabs
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _frames(n, seed=4):
+    return np.random.RandomState(seed).uniform(-1, 1, size=(n, 3, 256, 256)).astype(np.float32)
+
+
+def _landmarks(n):
+    from synth_weights import make_user_transform
+    return np.stack([make_user_transform((0.04 * (i + 1), -0.03 * i), 6.0 * (i - 1)) for i in range(n)]).astype(np.float32)
+
+
+@pytest.mark.parametrize('cfg,batch,steps', [('Rmini', 3, 5), ('Tmini', 2, 3)])
+def test_run_on_batch_matches_oracle(cfg, batch, steps):
+    from oracle import oracle as O
+    from torch_utils import _sg3abi
+    from utils.inference_utils import get_average_image, run_on_batch
+    net, opts, enc_sd, gen_sd, sched = build_restyle_pair(cfg, device=DEV, n_iters=steps)
+    lat_avg = gen_sd['mapping.w_avg']
+    x, lt = _frames(batch), _landmarks(batch)
+    avg_o = O.get_average_image(enc_sd, gen_sd, sched, lat_avg)
+    imgs_o, lats_o, aligned_last_o = O.run_on_batch(enc_sd, gen_sd, sched, x, lat_avg, avg_o, steps, landmarks_transform=lt)
+    n0 = _sg3abi.launch_count
+    with torch.no_grad():
+        avg = get_average_image(net)
+        assert avg.is_cuda and maxabs(avg.cpu().numpy(), avg_o) <= 1e-5
+        xt = torch.from_numpy(x).to(DEV)
+        imgs_on, lats_on = run_on_batch(xt, net, opts, avg, landmarks_transform=torch.from_numpy(lt).to(DEV))
+        imgs_off, lats_off = run_on_batch(xt, net, opts, avg, landmarks_transform=None)
+    assert _sg3abi.launch_count - n0 > 100 * steps, 'the loop did not run on the HIP kernels'
+    for it in range(steps):
+        lat_on = np.stack([lats_on[i][it] for i in range(batch)])
+        lat_off = np.stack([lats_off[i][it] for i in range(batch)])
+        tol = 2e-4 * float(np.abs(lats_o[it]).max())
+        assert maxabs(lat_on, lats_o[it]) <= tol, (it, maxabs(lat_on, lats_o[it]), tol)
+        assert maxabs(lat_off, lats_o[it]) <= tol, it                  # the latents never see the landmark transforms
+        img_on = torch.stack([imgs_on[i][it] for i in range(batch)]).cpu().numpy()
+        img_off = torch.stack([imgs_off[i][it] for i in range(batch)]).cpu().numpy()
+        assert maxabs(img_on, imgs_o[it]) <= 1e-4, (it, maxabs(img_on, imgs_o[it]))
+        # without transforms every step returns the aligned image: the oracle's per-step output except for the last step
+        assert maxabs(img_off, aligned_last_o if it == steps - 1 else imgs_o[it]) <= 1e-4, it
+    # the last step with transforms is the UNALIGNED render: it differs visibly from the aligned one
+    assert maxabs(imgs_o[-1], aligned_last_o) > 1e-3
+
+
+def test_restyle_full_size_first_step_and_batch_independence():
+    """BASELINE configs[2] shape: IR-SE50 encoder + FFHQ-1024 config-R decoder, batch 16, 5 steps.  (1) step 0 of
+    pSp.forward on the golden encoder input = golden encoder codes (reference residual units) + latent_avg; (2) the batch-16
+    loop gives every frame what a batch-1 loop gives it (frames are independent units: the sharding argument of SURVEY 8e)."""
+    import types
+    from models.setgan.encoder.psp3 import pSp
+    from synth_weights import synth_encoder_state_dict
+    from utils.inference_utils import get_average_image, run_on_batch
+    g = golden('encoder')
+    G = build_product_generator('R1024')
+    opts = types.SimpleNamespace(encoder_type='BackboneEncoder', input_nc=6, checkpoint_path=None, n_iters_per_batch=5, resize_outputs=False)
+    net = pSp(opts, decoder=G)
+    man = {k: list(v.shape) for k, v in net.encoder.state_dict().items()}
+    net.encoder.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth_encoder_state_dict(man, seed=0).items()})
+    net = net.eval().requires_grad_(False).to(DEV)
+    x6 = np.random.RandomState(3).uniform(-1, 1, size=(2, 6, 256, 256)).astype(np.float32)       # the golden encoder input
+    with torch.no_grad():
+        img, codes = net.forward(torch.from_numpy(x6).to(DEV), latent=None, return_latents=True, resize=False)
+        assert tuple(img.shape) == (2, 3, 1024, 1024) and bool(torch.isfinite(img).all())
+        want = g['codes'] + G.mapping.w_avg.numpy()[None, None]
+        assert maxabs(codes.cpu().numpy(), want) <= 2e-4 * float(np.abs(want).max())
+        avg = get_average_image(net)
+        x = torch.from_numpy(_frames(16, seed=11)).to(DEV)
+        imgs, lats = run_on_batch(x, net, opts, avg)
+        assert len(imgs[15]) == 5 and tuple(imgs[15][4].shape) == (3, 1024, 1024)
+        for i in (0, 7, 15):
+            imgs1, lats1 = run_on_batch(x[i:i + 1], net, opts, avg)
+            for it in range(5):
+                tol = 2e-4 * max(1.0, float(np.abs(lats1[0][it]).max()))
+                assert maxabs(lats[i][it], lats1[0][it]) <= tol, (i, it, maxabs(lats[i][it], lats1[0][it]))
+            assert maxabs(imgs[i][4].cpu().numpy(), imgs1[0][4].cpu().numpy()) <= 1e-4, i

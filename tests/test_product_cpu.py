@@ -187,3 +187,19 @@ def test_sg3generator_wrapper(tmp_path):
         pickle.dump(dict(G_ema=G), f)
     w2 = m.SG3Generator(checkpoint_path=str(tmp_path / 'g.pkl'), device='cpu')
     assert torch.equal(w2.decoder.synthesis.L0_36_16.weight, G.synthesis.L0_36_16.weight)
+
+
+@pytest.mark.parametrize('transpose', [False, True])
+def test_conv2d_gradfix_custom_op_second_order(transpose):
+    """with `enabled` set the convolutions go through _ConvNd, whose weight gradient must stay differentiable w.r.t.
+    x as well as dy (reference conv2d_gradfix.py:175-190).  gradgradcheck in fp64 against numerical second derivatives."""
+    from torch_utils.ops.conv2d_gradfix import _ConvNd
+    r = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 6, 7, generator=r, dtype=torch.float64, requires_grad=True)
+    w = torch.randn((3, 4, 3, 3) if transpose else (4, 3, 3, 3), generator=r, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(4, generator=r, dtype=torch.float64, requires_grad=True)
+    fn = lambda x_, w_, b_: _ConvNd.apply(x_, w_, b_, transpose, (2, 2) if transpose else (1, 1), (1, 1), (1, 1) if transpose else (0, 0), (1, 1), 1)  # noqa: E731
+    want = (torch.nn.functional.conv_transpose2d(x, w, b, 2, 1, 1) if transpose else torch.nn.functional.conv2d(x, w, b, 1, 1))
+    assert torch.allclose(fn(x, w, b), want)
+    assert torch.autograd.gradcheck(fn, (x, w, b))
+    assert torch.autograd.gradgradcheck(fn, (x, w, b))
