@@ -115,18 +115,30 @@ class KernelTimer:
         return float(np.median(steps)) if steps else 0.0
 
 
-def cpu_baseline(cfg):
-    """CPU oracle (oracle/: C + OpenMP restatement of the reference's ref path) on ONE image of the same workload."""
+def cpu_baseline(cfg, runs=3):
+    """CPU oracle (oracle/: C + OpenMP restatement of the reference's ref path) on ONE image of the same workload: one warm-up
+    forward, then the median of `runs` timed forwards."""
     from helpers import build_oracle_generator
     from oracle import oracle as O
     from synth_weights import synth_ws
     sd, sched = build_oracle_generator(cfg)
     ws = synth_ws(1, sched['num_ws'], sched['w_dim'], seed=1)
-    t0 = time.time()
-    O.synthesis(sd, sched, ws=ws)
-    dt = time.time() - t0
+    times = []
+    for i in range(runs + 1):
+        t0 = time.time()
+        O.synthesis(sd, sched, ws=ws)
+        times.append(time.time() - t0)
+    dt = float(np.median(times[1:]))
     return dict(value=1.0 / dt, unit='imgs/s', cores=O.num_threads(), kind='port',
-                sample=f'1 image, {cfg} synthesis forward fp32, {dt:.1f} s on {O.num_threads()} OpenMP threads')
+                sample=f'1 image per run, {cfg} synthesis forward fp32; warm-up {times[0]:.1f} s, then median of {runs} runs = {dt:.1f} s '
+                       f'({", ".join(f"{t:.1f}" for t in times[1:])}) on {O.num_threads()} OpenMP threads')
+
+
+def kernel_source_sha():
+    """Fingerprint of the filtered_lrelu kernel source: PMC traffic figures are only quoted for the source they were collected on."""
+    import hashlib
+    with open(os.path.join(ROOT, 'stylegan3-editing_amd', 'csrc', 'sg3_filtered_lrelu.hip'), 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def bench_inversion(G, device, rank, world, frames_per_gpu=16, restyle_steps=5, reps=2, decoder='T-1024'):
@@ -411,12 +423,15 @@ def main(argv=None):
         conv_ms = timer.median_step_ms('modulated_conv2d', n_layers + 1)
         achieved = total_bytes / (fl_ms * 1e-3) / 1e9 if fl_ms > 0 else 0.0
         # HBM traffic of the same 14 launches from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes over this
-        # command, summarised by tools/sum_traffic.py); only valid for the default workload
+        # command, summarised by tools/sum_traffic.py, which stamps the kernel source it ran on); only valid for the default workload
+        # and for THIS kernel source -- a stale file reads as null
         traffic = None
         tfile = os.path.join(ROOT, 'profiles', 'flrelu_traffic.json')
         if os.path.exists(tfile) and args.batch == 8 and args.config == 'T1024':
             with open(tfile) as f:
-                traffic = json.load(f)['traffic_bytes_per_step']
+                tj = json.load(f)
+            if tj.get('kernel_source_sha') == kernel_source_sha():
+                traffic = tj['traffic_bytes_per_step']
         inp = G.synthesis.input
         conv_flop = 2 * inp.channels * inp.channels * int(inp.size[0]) * int(inp.size[1]) * args.batch
         for name in G.synthesis.layer_names:

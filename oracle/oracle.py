@@ -485,16 +485,7 @@ def backbone_encoder(sd, x, num_layers=50, n_styles=16, return_feats=False):
             h = bottleneck_ir_se(sd, f'body.{i}.', h, 2 if u == 0 else 1)
             feats[f'body{i}'] = h
             i += 1
-    codes = []
-    for j in range(n_styles):
-        t = h
-        for c in (0, 2, 4, 6):                                                        # map2style.py:15-19
-            t = conv2d(t, sd[f'styles.{j}.convs.{c}.weight'], sd[f'styles.{j}.convs.{c}.bias'], 2, 1)
-            t = np.where(t >= 0, t, t * np.float32(0.01)).astype(np.float32)          # nn.LeakyReLU() default slope
-        t = t.reshape(-1, t.shape[1])
-        w = sd[f'styles.{j}.linear.weight'] * np.float32(1.0 / np.sqrt(t.shape[1]))   # EqualLinear, lr_mul = 1
-        codes.append(t @ w.T + sd[f'styles.{j}.linear.bias'][None])
-    codes = np.stack(codes, axis=1).astype(np.float32)
+    codes = _style_heads(sd, h, n_styles)
     return (codes, feats) if return_feats else codes
 
 

@@ -27,11 +27,15 @@
 //   Global reads are issued 3 rows ahead into registers; reads and writes are 256-B contiguous per instruction.
 //   Grid = planes x row-chunks x strips, renumbered so that blocks sharing halo columns/rows sit on one XCD (L2).
 //
-// Supported by the streaming kernel (everything the StyleGAN3 forward needs): separable fu/fd with
-// (up, down, fuTaps, fdTaps) in {(2,2,12,12), (4,2,24,12)}, fp32 / fp16 I/O, unit innermost stride, no sign
-// tensor.  `flrelu_pointwise_kernel` covers up = down = 1 with 1x1 filters (the ToRGB layer).  Anything else
-// (2-D radial filters of config R, sign write/read for backward, other factors) returns SG3_NO_KERNEL and the
-// caller composes upfirdn2d + filtered_lrelu_act + upfirdn2d, exactly like the reference's rc = -1 path.
+// Supported by the streaming kernel (`stream_supported` / `stream_params_ok` below are the authority): fp32 / fp16 I/O with
+// unit innermost stride, slope in [0,1], and
+//   forward, plain or sign-writing (training):  up 2 (12 taps) | up 4 (24 taps), separable;  down 2 with a separable 12-tap
+//       filter (config T, and the critically sampled layers of config R) or a full 12x12 filter (radial layers of config R;
+//       RADIAL 1|2, or 5|6 when the caller promises mirror-symmetric rows);
+//   adjoint (sign-reading):  up 2 with a separable 12-tap filter or a full 12x12 filter (RADIAL 3|4: the radial layers' down
+//       filter ends up on the up side), down 2 (12 taps) | down 4 (24 taps), separable.
+// `flrelu_pointwise_kernel` covers up = down = 1 with 1x1 filters (the ToRGB layer).  Anything else returns SG3_NO_KERNEL and
+// the caller composes upfirdn2d + filtered_lrelu_act + upfirdn2d, exactly like the reference's rc = -1 path.
 //
 // Algorithmic traffic: C*(xH*xW + yH*yW)*sizeof(T) bytes per image -- the roofline figure bench.py uses.
 #include "sg3_common.h"

@@ -42,10 +42,17 @@ class PTI:
             raise RuntimeError('PTI: opts.lpips_lambda > 0 needs an lpips_loss callable (the pretrained LPIPS network is external)')
         self.history = []                                 # (step, loss, lpips, l2) floats of the last optimize_model call
 
+    @staticmethod
+    def tunable_parameters(generator):
+        """Everything in `synthesis` except the three parameters of the Fourier-feature input (its mixing weight and the affine
+        that predicts the transform), which stay frozen as in the reference (:111-114)."""
+        frozen = {id(p) for p in generator.synthesis.input.parameters()}
+        tunable = [p for p in generator.synthesis.parameters() if id(p) not in frozen]
+        assert len(tunable) == len(list(generator.synthesis.parameters())) - 3
+        return tunable
+
     def get_optimizer(self, generator):
-        # do not alter the fourier features
-        params = list(generator.synthesis.parameters())[3:]
-        return torch.optim.Adam(params, lr=self.opts.learning_rate)
+        return torch.optim.Adam(self.tunable_parameters(generator), lr=self.opts.learning_rate)
 
     def optimize_model(self, generator, codes, target_images, landmarks_transforms=None, image_name=None):
         optimizer = self.get_optimizer(generator)
@@ -71,22 +78,16 @@ class PTI:
         return outputs
 
     def calc_loss(self, generated_images, real_images):
-        loss = 0.0
-        loss_lpips = None
-        l2_loss_val = None
-        if self.opts.l2_lambda > 0:
-            l2_loss_val = self.mse_loss(generated_images, real_images)
-            loss += l2_loss_val * self.opts.l2_lambda
-        if self.opts.lpips_lambda > 0:
-            loss_lpips = self.lpips_loss(generated_images, real_images)
-            loss += loss_lpips * self.opts.lpips_lambda
-        return loss, loss_lpips, l2_loss_val
+        """(total, lpips term or None, l2 term or None): total = l2_lambda * MSE + lpips_lambda * LPIPS, each term only when its
+        weight is positive (reference :167-177)."""
+        terms = {'l2': (self.opts.l2_lambda, self.mse_loss), 'lpips': (self.opts.lpips_lambda, self.lpips_loss)}
+        values = {name: (fn(generated_images, real_images) if weight > 0 else None) for name, (weight, fn) in terms.items()}
+        total = sum(terms[name][0] * v for name, v in values.items() if v is not None) if any(v is not None for v in values.values()) else 0.0
+        return total, values['lpips'], values['l2']
 
     @staticmethod
     def get_description(step, loss, lpips_loss, l2_loss_val):
-        desc = f'Step: {step} - Loss: {loss.item():.4f}'
-        if lpips_loss is not None:
-            desc += f', LPIPS: {lpips_loss.item():.4f}'
-        if l2_loss_val is not None:
-            desc += f', L2: {l2_loss_val.item():.4f}'
-        return desc
+        """Progress line of the reference (:179-186): 'Step: N - Loss: x[, LPIPS: y][, L2: z]'."""
+        parts = [f'Step: {step} - Loss: {loss.item():.4f}']
+        parts += [f'{label}: {value.item():.4f}' for label, value in (('LPIPS', lpips_loss), ('L2', l2_loss_val)) if value is not None]
+        return ', '.join(parts)

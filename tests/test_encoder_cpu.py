@@ -126,3 +126,95 @@ def test_e4e_progressive_encoder_combination():
         c = prog(x)
         assert maxabs(c[:, 3].numpy(), (a[:, 0] + a[:, 3]).numpy()) <= 1e-6 and maxabs(c[:, 4].numpy(), a[:, 0].numpy()) <= 1e-6
     assert issubclass(e4e, torch.nn.Module) and e4e.forward is not None
+
+
+def _resnet34_expected_keys(n_styles):
+    """state_dict keys of the reference ResNetBackboneEncoder: its own stem + torchvision resnet34's layer1..4 BasicBlocks
+    flattened into `body` (reference restyle_psp_encoders.py:61-83) + the style heads."""
+    bn = ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked')
+    keys = ['conv1.weight'] + [f'bn1.{b}' for b in bn] + ['relu.weight']
+    i = 0
+    for count, projected in ((3, False), (4, True), (6, True), (3, True)):
+        for u in range(count):
+            keys += [f'body.{i}.conv1.weight'] + [f'body.{i}.bn1.{b}' for b in bn] + [f'body.{i}.conv2.weight'] + [f'body.{i}.bn2.{b}' for b in bn]
+            if projected and u == 0:
+                keys += [f'body.{i}.downsample.0.weight'] + [f'body.{i}.downsample.1.{b}' for b in bn]
+            i += 1
+    for j in range(n_styles):
+        for c in (0, 2, 4, 6):
+            keys += [f'styles.{j}.convs.{c}.weight', f'styles.{j}.convs.{c}.bias']
+        keys += [f'styles.{j}.linear.weight', f'styles.{j}.linear.bias']
+    return keys
+
+
+def build_resnet_encoder(n_styles=4, device='cpu', progressive=False):
+    from models.setgan.encoder.encoders.restyle_e4e_encoders import ResNetProgressiveBackboneEncoder
+    from models.setgan.encoder.encoders.restyle_psp_encoders import ResNetBackboneEncoder
+    opts = types.SimpleNamespace(input_nc=6)
+    enc = (ResNetProgressiveBackboneEncoder(n_styles, opts) if progressive else ResNetBackboneEncoder(n_styles, opts)).eval().requires_grad_(False)
+    man = {k: list(v.shape) for k, v in enc.state_dict().items()}
+    sd = synth_encoder_state_dict(man, seed=2)
+    enc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return enc.to(device), {k: np.asarray(v) for k, v in sd.items()}
+
+
+def test_resnet34_encoder_keys_and_oracle():
+    """ResNetBackboneEncoder (reference restyle_psp_encoders.py:53-97): checkpoint-compatible keys and shapes, product
+    (plain PyTorch path) against the oracle restatement, e4e's progressive combination on the same trunk."""
+    from oracle import oracle as O
+    enc, sd = build_resnet_encoder(4)
+    assert list(enc.state_dict().keys()) == _resnet34_expected_keys(4)
+    shapes = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    assert shapes['conv1.weight'] == (64, 6, 7, 7) and shapes['body.3.downsample.0.weight'] == (128, 64, 1, 1)
+    assert shapes['body.7.conv1.weight'] == (256, 128, 3, 3) and shapes['body.15.conv2.weight'] == (512, 512, 3, 3)
+    x = _input()[:1]
+    with torch.no_grad():
+        codes = enc(torch.from_numpy(x))
+    ref, feats = O.resnet_backbone_encoder(sd, x, n_styles=4, return_feats=True)
+    assert feats['stem'].shape == (1, 64, 128, 128) and feats['body15'].shape == (1, 512, 16, 16)
+    assert tuple(codes.shape) == (1, 4, 512)
+    assert maxabs(codes.numpy(), ref) <= 2e-4 * max(1.0, float(np.abs(ref).max()))
+    prog, _ = build_resnet_encoder(4, progressive=True)
+    with torch.no_grad():
+        b = prog(torch.from_numpy(x))
+    assert maxabs(b[:, 0].numpy(), codes[:, 0].numpy()) <= 1e-6 and maxabs(b[:, 2].numpy(), (codes[:, 0] + codes[:, 2]).numpy()) <= 1e-5
+
+
+def test_inference_iterative_writes_latents_and_stats(tmp_path):
+    """The on-disk contract of reference inversion/scripts/inference_iterative.py:61-101: `latents.npy` holds
+    {image name: [one [16,512] latent per ReStyle step]} and `stats.txt` 'Runtime mean+-std' of the per-batch time."""
+    import re
+    from helpers import build_product_generator
+    from inversion.scripts.inference_iterative import run_inference
+    from models.setgan.encoder.psp3 import pSp
+    from utils.inference_utils import get_average_image, run_on_batch
+
+    class TinyEncoder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(6, 16 * 32)
+
+        def forward(self, x):
+            return self.lin(x.mean(dim=(2, 3))).view(-1, 16, 32) * 0.1
+
+    G = build_product_generator('Ttiny')
+    opts = types.SimpleNamespace(encoder_type='BackboneEncoder', input_nc=6, checkpoint_path=None, n_iters_per_batch=3, resize_outputs=False, test_batch_size=2)
+    torch.manual_seed(0)
+    net = pSp.__new__(pSp)
+    torch.nn.Module.__init__(net)
+    net.opts, net.n_styles, net.encoder, net.decoder = opts, 16, TinyEncoder(), G
+    net.face_pool = torch.nn.AdaptiveAvgPool2d((256, 256))
+    net.latent_avg = G.mapping.w_avg
+    net.eval()
+    images = torch.rand(5, 3, 256, 256) * 2 - 1
+    names = [f'{i:05d}.png' for i in range(5)]
+    results, latents, line = run_inference(net, opts, images, names, str(tmp_path), n_images=None)
+    assert re.fullmatch(r'Runtime \d+\.\d{4}\+-\d+\.\d{4}', line)
+    assert open(tmp_path / 'stats.txt').read() == line
+    loaded = np.load(tmp_path / 'latents.npy', allow_pickle=True).item()
+    assert list(loaded.keys()) == names                          # insertion order = dataset order
+    assert all(len(v) == 3 and v[0].shape == (16, 32) and v[0].dtype == np.float32 for v in loaded.values())
+    with torch.no_grad():
+        _, direct = run_on_batch(images[4:5], net, opts, get_average_image(net))     # the ragged last batch (5 = 2 + 2 + 1)
+    assert maxabs(loaded['00004.png'][2], direct[0][2]) <= 1e-6
+    assert len(results['00000.png']) == 3 and tuple(results['00000.png'][0].shape) == (3, 64, 64)

@@ -137,3 +137,28 @@ def test_packed_weights_follow_parent_load_and_inplace_updates():
         third = net.encoder(x)
         assert maxabs(third.cpu().numpy(), net.encoder._forward_torch(x).cpu().numpy()) <= 2e-3
         assert maxabs(third.cpu().numpy(), second.cpu().numpy()) > 1e-3
+
+
+def test_resnet34_encoder_hip_path():
+    """ResNetBackboneEncoder / ResNetProgressiveBackboneEncoder on the matrix-core convolution (BasicBlocks: BN folded, ReLU in
+    the epilogue, 1x1 stride-2 projections) against the oracle restatement and the plain PyTorch path of the same modules."""
+    from oracle import oracle as O
+    from test_encoder_cpu import build_resnet_encoder
+    from torch_utils import _sg3abi
+    enc, sd = build_resnet_encoder(4, device=DEV)
+    x = _input()
+    ref = O.resnet_backbone_encoder(sd, x, n_styles=4)
+    n0 = _sg3abi.launch_count
+    with torch.no_grad():
+        codes = enc(torch.from_numpy(x).to(DEV))
+        assert _sg3abi.launch_count - n0 >= 16 * 2 + 3, 'the fused HIP path did not run'
+        torch_path = enc._forward_torch(torch.from_numpy(x).to(DEV))
+    assert tuple(codes.shape) == (2, 4, 512)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert maxabs(codes.cpu().numpy(), ref) <= 2e-4 * scale
+    assert maxabs(codes.cpu().numpy(), torch_path.cpu().numpy()) <= 2e-3 * scale
+    prog, _ = build_resnet_encoder(4, device=DEV, progressive=True)
+    with torch.no_grad():
+        b = prog(torch.from_numpy(x).to(DEV))
+    assert maxabs(b[:, 0].cpu().numpy(), codes[:, 0].cpu().numpy()) <= 1e-5 * scale
+    assert maxabs(b[:, 3].cpu().numpy(), (codes[:, 0] + codes[:, 3]).cpu().numpy()) <= 1e-5 * scale

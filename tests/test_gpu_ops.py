@@ -257,7 +257,7 @@ def test_filtered_lrelu_fused_sign_kernels_fp16_io(shape, up, taps, pad, radial)
     y = fl.filtered_lrelu(x, T(fu), T(fd), b, **kw)
     assert y.dtype == torch.float16
     (y.float() * gy.to(DEV).float()).sum().backward()
-    scale = max(1.0, float(yr.abs().max()))
+    scale = max(1.0, float(yr.detach().abs().max()))
     assert maxabs(y0.float().cpu().numpy(), yr.detach().numpy()) <= 1e-3 * scale
     assert maxabs(y.detach().float().cpu().numpy(), yr.detach().numpy()) <= 1e-3 * scale
     assert x.grad.dtype == torch.float16

@@ -77,7 +77,7 @@ def test_restyle_full_size_first_step_and_batch_independence():
     with torch.no_grad():
         img, codes = net.forward(torch.from_numpy(x6).to(DEV), latent=None, return_latents=True, resize=False)
         assert tuple(img.shape) == (2, 3, 1024, 1024) and bool(torch.isfinite(img).all())
-        want = g['codes'] + G.mapping.w_avg.numpy()[None, None]
+        want = g['codes'] + G.mapping.w_avg.cpu().numpy()[None, None]
         assert maxabs(codes.cpu().numpy(), want) <= 2e-4 * float(np.abs(want).max())
         avg = get_average_image(net)
         x = torch.from_numpy(_frames(16, seed=11)).to(DEV)

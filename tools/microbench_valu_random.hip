@@ -7,6 +7,8 @@
 //   mode 2  the arithmetic of one flrelu up-2 row per trip: 8 samples from LDS (random table, address moves with the trip),
 //           H-up 2 x (mul + 5 fma), V-up 2 rows x 2 x (mul + 5 fma), lrelu + clamp (pk_mul, 4 max, 4 med3), V-down 2 x 12 fma,
 //           one LDS row hand-off + 12-tap H-down per trip; taps in scalar registers; no global traffic in the loop
+//   mode 3  mode 2 + the kernel's HBM stream: per row every lane loads 2 dwords (prefetched three rows ahead) and stores one
+//           8-byte pair, each wave walking its own region of a 4 GiB buffer (8 B in + 8 B out per lane and row, like an up-2 layer)
 // Build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/microbench_valu_random.hip -o /tmp/mv && /tmp/mv
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -14,6 +16,9 @@
 #include <vector>
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_f;          // explicit LDS address space: ds_* instructions, not flat_*
+typedef __attribute__((address_space(3))) v2f lds_v2f;
+typedef __attribute__((address_space(3))) v4f lds_v4f;
 
 struct Taps { float t[12]; };
 
@@ -25,17 +30,19 @@ __device__ __forceinline__ float rnd(unsigned i) {
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(256) k(float* out, unsigned long long* stamps, int iters, Taps tp) {
+__global__ void __launch_bounds__(256) k(float* out, unsigned long long* stamps, int iters, Taps tp, const float* gin, float* gout, unsigned gmask) {
     __shared__ __attribute__((aligned(16))) float sm[4 * 1024 + 4 * 512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* tab = sm + wave * 1024;                  // this wave's random table
-    float* row = sm + 4096 + wave * 512;            // this wave's hand-off row
+    lds_f* tab = (lds_f*)sm + wave * 1024;          // this wave's random table
+    lds_f* row = (lds_f*)sm + 4096 + wave * 512;    // this wave's hand-off row
     for (int i = lane; i < 1024; i += 64) tab[i] = rnd(i + 1024 * (blockIdx.x * 4 + wave));
     for (int i = lane; i < 512; i += 64) row[i] = 0.f;
     __syncthreads();
-    v2f x[8], acc[8];
+    v2f x[8], acc[12];
 #pragma unroll
     for (int i = 0; i < 8; i++) { x[i] = (v2f){rnd(threadIdx.x * 16 + 2 * i + blockIdx.x * 7919), rnd(threadIdx.x * 16 + 2 * i + 1 + blockIdx.x * 104729)}; acc[i] = MODE == 0 ? x[i] + splat((float)i) : splat(0.f); }
+#pragma unroll
+    for (int i = 8; i < 12; i++) acc[i] = splat(0.f);
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     if (MODE == 0) {
         const v2f va = splat(tp.t[0]), vb = splat(tp.t[1]);
@@ -50,17 +57,32 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* stamps,
             for (int r = 0; r < 12; r++)
 #pragma unroll
                 for (int i = 0; i < 8; i++) acc[i] = fma2(x[(i + r) & 7], splat(tp.t[r]), acc[i]);
-    } else {
+    } else if (MODE >= 2) {
         v2f w[6][2];
 #pragma unroll
         for (int s = 0; s < 6; s++) { w[s][0] = x[s]; w[s][1] = x[(s + 2) & 7]; }
+        // mode 3: this wave's stream position (floats); rows are 128 floats in, 128 floats out
+        const unsigned wid = (blockIdx.x * 4 + wave);
+        unsigned gpos = wid * (unsigned)(iters * 6 * 128);
+        float pre[3][2];
+        if (MODE == 3) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) { pre[r][0] = gin[((gpos + r * 128) & gmask) + lane]; pre[r][1] = gin[((gpos + r * 128) & gmask) + 64 + lane]; }
+        }
         for (int it = 0; it < iters; it++) {
 #pragma unroll
             for (int S = 0; S < 6; S++) {             // six rows per trip, window slots resolved at compile time
                 const int base = ((it * 6 + S) * 16 + 2 * lane) & 1015;
+                if (MODE == 3) {
+                    // the staged input row goes through LDS like the kernel's (two dword writes), next row requested
+                    tab[(base + 512) & 1023] = pre[S % 3][0]; tab[(base + 640) & 1023] = pre[S % 3][1];
+                    const unsigned nxt = (gpos + 3 * 128) & gmask;
+                    pre[S % 3][0] = gin[nxt + lane]; pre[S % 3][1] = gin[nxt + 64 + lane];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
                 float xs[8];
 #pragma unroll
-                for (int q = 0; q < 4; q++) { const v2f t = *reinterpret_cast<const volatile v2f*>(tab + base + 2 * q); xs[2 * q] = t.x; xs[2 * q + 1] = t.y; }
+                for (int q = 0; q < 4; q++) { const v2f t = *reinterpret_cast<const volatile lds_v2f*>(tab + base + 2 * q); xs[2 * q] = t.x; xs[2 * q + 1] = t.y; }
 #pragma unroll
                 for (int g = 0; g < 2; g++) {
                     v2f a = splat(xs[g]) * (v2f){tp.t[0], tp.t[1]};
@@ -80,21 +102,22 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* stamps,
                     const v2f r0v = {a[0], a[1]}, r1v = {a[2], a[3]};
 #pragma unroll
                     for (int r = 0; r < 6; r++) {
-                        const int slot = (S + j + r) % 4;
+                        const int slot = (S + 5 - r) % 6;          // six output rows in flight, as in the kernel
                         acc[2 * slot] = fma2(r0v, splat(tp.t[2 * r + j]), acc[2 * slot]);
                         acc[2 * slot + 1] = fma2(r1v, splat(tp.t[2 * r + j]), acc[2 * slot + 1]);
                     }
                 }
                 // completed output row: hand-off through LDS, 12-tap H-down, result folded back into the oldest accumulator
-                const int slot = S % 4;
-                *reinterpret_cast<volatile v4f*>(row + 4 + 4 * lane) = (v4f){acc[2 * slot].x, acc[2 * slot].y, acc[2 * slot + 1].x, acc[2 * slot + 1].y};
+                const int slot = S % 6;
+                *reinterpret_cast<volatile lds_v4f*>(row + 4 + 4 * lane) = (v4f){acc[2 * slot].x, acc[2 * slot].y, acc[2 * slot + 1].x, acc[2 * slot + 1].y};
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 v2f pr[8];
 #pragma unroll
-                for (int q = 0; q < 4; q++) { const v4f t = *reinterpret_cast<const volatile v4f*>(row + 4 * ((lane + q) & 63)); pr[2 * q] = (v2f){t.x, t.y}; pr[2 * q + 1] = (v2f){t.z, t.w}; }
+                for (int q = 0; q < 4; q++) { const v4f t = *reinterpret_cast<const volatile lds_v4f*>(row + 4 * ((lane + q) & 63)); pr[2 * q] = (v2f){t.x, t.y}; pr[2 * q + 1] = (v2f){t.z, t.w}; }
                 v2f y0 = pr[0] * (v2f){tp.t[0], tp.t[1]}, y1 = pr[1] * (v2f){tp.t[0], tp.t[1]};
 #pragma unroll
                 for (int q = 1; q < 6; q++) { y0 = fma2(pr[q], (v2f){tp.t[2 * q], tp.t[2 * q + 1]}, y0); y1 = fma2(pr[q + 1], (v2f){tp.t[2 * q], tp.t[2 * q + 1]}, y1); }
+                if (MODE == 3) { *reinterpret_cast<v2f*>(gout + (gpos & gmask) + 2 * lane) = (v2f){y0.x + y0.y, y1.x + y1.y}; gpos += 128; }
                 acc[2 * slot] = (v2f){(y0.x + y0.y) * 0.01f, (y1.x + y1.y) * 0.01f};      // keeps the accumulators bounded
                 acc[2 * slot + 1] = splat(0.f);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -104,19 +127,19 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* stamps,
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) s += acc[i].x + acc[i].y;
+    for (int i = 0; i < 12; i++) s += acc[i].x + acc[i].y;
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (lane == 0) { stamps[2 * (blockIdx.x * 4 + wave)] = c1 - c0; stamps[2 * (blockIdx.x * 4 + wave) + 1] = r1 - r0; }
 }
 
 template <int MODE>
-static void run(const char* name, int bpc, int iters, double pkPerIter, float* d, unsigned long long* st, Taps tp) {
+static void run(const char* name, int bpc, int iters, double pkPerIter, float* d, unsigned long long* st, Taps tp, const float* gin = nullptr, float* gout = nullptr, unsigned gmask = 0) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int blocks = 256 * bpc;
     float ms = 0; double total = 0;
     while (total < 1000.0) {
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, st, iters, tp);
+        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, st, iters, tp, gin, gout, gmask);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&ms, e0, e1); total += ms;
     }
@@ -135,6 +158,16 @@ static void run(const char* name, int bpc, int iters, double pkPerIter, float* d
 int main() {
     float* d; unsigned long long* st;
     (void)hipMalloc(&d, 256 * 8 * 256 * 4); (void)hipMalloc(&st, 256 * 8 * 4 * 16);
+    // 4 GiB in + 4 GiB out: far beyond the 256 MiB Infinity Cache; random input significands
+    const unsigned gfloats = 1u << 30, gmask = gfloats - 1;             // stream positions (multiples of 128 floats) wrap inside the buffers
+    float *gin, *gout;
+    (void)hipMalloc(&gin, (size_t)gfloats * 4 + 4096); (void)hipMalloc(&gout, (size_t)gfloats * 4 + 4096);
+    {
+        std::vector<float> h(1 << 24);
+        unsigned sd = 99u;
+        for (auto& v : h) { sd = sd * 1664525u + 1013904223u; v = ((int)(sd >> 8) - 0x800000) * (1.0f / 8388608.0f); }
+        for (size_t off = 0; off < gfloats; off += h.size()) (void)hipMemcpy(gin + off, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    }
     Taps smooth; for (int i = 0; i < 12; i++) smooth.t[i] = 0; smooth.t[0] = 1.0001f; smooth.t[1] = 0.5f;
     Taps rt = {{0.7391f, -0.3127f, 0.4513f, -0.6589f, 0.2071f, -0.4259f, 0.1873f, -0.5311f, 0.3499f, -0.2203f, 0.6113f, -0.1871f}};
     for (int bpc = 2; bpc <= 8; bpc *= 2) {
@@ -142,6 +175,7 @@ int main() {
         run<1>("pk_fma random, registers", bpc, 4000, 96, d, st, rt);
         // packed-FMA-class instructions per trip (6 rows): H-up 12, V-up 24, slope mul 2 x 2, V-down 24, H-down 12 -> 76 per row
         run<2>("flrelu up-2 row arithmetic + LDS", bpc, 700, 6 * 76, d, st, rt);
+        run<3>("... + HBM stream 8 B in / 8 B out", bpc, 700, 6 * 76, d, st, rt, gin, gout, gmask);
     }
     return 0;
 }

@@ -9,7 +9,9 @@ a coalesced streaming read, so it is doubled (checked on this kernel: 2 x FETCH_
 bytes, the expected halo / warm-up over-fetch; WRITE_SIZE = 1.01 x the algorithmic write bytes).
 """
 import csv
+import hashlib
 import json
+import os
 import sys
 
 
@@ -23,7 +25,9 @@ def per_forward(path, counter):
 
 fetch = 2.0 * per_forward(sys.argv[1], 'FETCH_SIZE')
 write = per_forward(sys.argv[2], 'WRITE_SIZE')
-out = dict(fetch_bytes_per_step=fetch, write_bytes_per_step=write, traffic_bytes_per_step=fetch + write,
+src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'stylegan3-editing_amd', 'csrc', 'sg3_filtered_lrelu.hip')
+sha = hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16]       # bench.py quotes the figure only for this kernel source
+out = dict(fetch_bytes_per_step=fetch, write_bytes_per_step=write, traffic_bytes_per_step=fetch + write, kernel_source_sha=sha,
            note='one batch-8 T1024 forward, 14 filtered_lrelu launches; FETCH_SIZE doubled per the gfx950 correction')
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print(out)
