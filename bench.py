@@ -36,6 +36,7 @@ custom_ops.verbosity = 'none'     # stdout carries exactly one line: the JSON re
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F16_PEAK_TFLOPS = 2500.0   # same guide: dense fp16 / bf16 MFMA peak (the headline figure with 2:1 sparsity is not used)
+ENCODER_GFLOP_PER_IMAGE = 72.3   # IR-SE50 trunk 65.9 + 16 GradualStyleBlock heads 6.4 GFLOP per 256x256 image and ReStyle step
 
 
 def build_generator(cfg, device):
@@ -172,8 +173,24 @@ def bench_inversion(G, device, rank, world, frames_per_gpu=16, restyle_steps=5, 
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert tuple(lat.shape) == (n_frames, 16, 512) and bool(torch.isfinite(lat).all())
+    # encoder alone (one ReStyle step's encoder forward over this rank's frames): HIP events on the launch stream
+    x6 = torch.cat([frames[:frames_per_gpu], frames[:frames_per_gpu]], dim=1)
+    with torch.no_grad():
+        for _ in range(2):
+            net.encoder(x6)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            net.encoder(x6)
+        e1.record()
+        torch.cuda.synchronize()
+    enc_ms = e0.elapsed_time(e1) / 5
+    enc_tflops = ENCODER_GFLOP_PER_IMAGE * frames_per_gpu / enc_ms         # GFLOP / ms = TFLOP/s
+    encoder = {'bound': 'mfma', 'kernel': 'conv2d_f16x3_kernel (IR-SE50 trunk) + head GEMMs', 'achieved': 3 * enc_tflops, 'peak': MFMA_F16_PEAK_TFLOPS,
+               'unit': 'TFLOP/s', 'frac': 3 * enc_tflops / MFMA_F16_PEAK_TFLOPS, 'algorithmic': enc_tflops,
+               'algorithmic_flop_per_image': ENCODER_GFLOP_PER_IMAGE * 1e9, 'ms_per_forward': enc_ms, 'batch': frames_per_gpu}
     return dict(metric='ReStyle-pSp video-inversion frames/sec', value=n_frames * reps / float(t.item()), unit='frames/s',
-                frames_per_gpu=frames_per_gpu, restyle_steps=restyle_steps, scaling='weak',
+                frames_per_gpu=frames_per_gpu, restyle_steps=restyle_steps, scaling='weak', encoder=encoder,
                 workload=f'IR-SE50 encoder + FFHQ-1024 config-{decoder} decoder (fp32), 5 ReStyle steps per frame, frames sharded over '
                          'ranks, all-gather of [F,16,512] latents; synthetic weights')
 

@@ -178,7 +178,8 @@ conv2d_pack_kernel(const float* w, const float* outScale, float* wp, int O, int 
 }
 
 // ---------------------------------------------------------------------------
-// Split-precision form for the 3x3 stride-1 convolutions that carry the backbone's FLOPs (same arithmetic as
+// Split-precision form for the 3x3 convolutions (stride 1: the backbone's FLOPs; stride 2: the first unit of every stage, the
+// ResNet34 blocks, with the patch columns de-interleaved in LDS so that the stride-2 im2col read stays conflict-free) (same arithmetic as
 // modconv_f16x3_kernel in sg3_modconv.hip: x = hi + lo in fp16, Ah*Bh + Ah*Bl + Al*Bh on v_mfma_f32_32x32x16_f16, fp32
 // accumulation, fp32-equivalent).  No bound on BatchNorm-ed activations is known ahead of time and none is needed for
 // accuracy (fp16's exponent range covers 6e-5 .. 65504 at full split precision, smaller magnitudes lose only bits that
@@ -186,13 +187,14 @@ conv2d_pack_kernel(const float* w, const float* outScale, float* wp, int O, int 
 // staging and raises `*flag` when it exceeds the fp16 range -- the caller then repeats the layer stack on the exact
 // fp32 kernel (torch_utils/ops/plain_conv.py).  Weights are packed [O][I/16][tap][hi|lo][16] halfs by
 // conv2d_pack_f16x3_kernel with the folded BatchNorm scale applied before the split.
-template <int WM, int WN, int TM, int TN>
+template <int STRIDE, int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(256, (TM * TN <= 4) ? 2 : 1)
 conv2d_f16x3_kernel(PlainConvParams p, int* flag) {
     constexpr int KS = 3, TAPS = 9, KC = 16;
     constexpr int BM = WM * TM * 32;
     constexpr int ROWS = WN * TN;
-    constexpr int PH = ROWS + KS - 1, PW = 32 + KS - 1;
+    constexpr int PH = (ROWS - 1) * STRIDE + KS, PW = 31 * STRIDE + KS;
+    constexpr int PWE = (PW + 1) / 2;                  // stride 2: even patch columns first (PWE of them), then the odd ones
     constexpr int NPIX = PH * PW;
     constexpr int AS = TAPS * 32 + 8;
     constexpr int AROW_V = TAPS * 32 / 8;
@@ -237,10 +239,11 @@ conv2d_f16x3_kernel(PlainConvParams p, int* flag) {
     for (int q = 0; q < PX_PER; q++) {
         const int e = tid + 256 * q;
         const int px = e % PW, py = e / PW;
-        const int gy = y0 - p.pad + py, gx = x0 - p.pad + px;
+        const int gy = y0 * STRIDE - p.pad + py, gx = x0 * STRIDE - p.pad + px;
         const bool ok = e < NPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
         bG[q] = ok ? (unsigned)(gy * p.W + gx) * 4u : 0x80000000u;
-        bL[q] = e < NPIX ? e * 8 : -1;
+        const int pcol = STRIDE == 1 ? px : (px & 1) * PWE + (px >> 1);
+        bL[q] = e < NPIX ? (py * PW + pcol) * 8 : -1;
         bM[q] = ok ? 1.f : 0.f;
     }
 
@@ -331,7 +334,9 @@ conv2d_f16x3_kernel(PlainConvParams p, int* flag) {
         }
 #pragma unroll
         for (int b = 0; b < TN; b++) {
-            const _Float16* src = sB + (lh * 2) * BPLANE + ((wn * TN + b + ky) * PW + li + kx) * 8;
+            // stride 2: patch column 2 * li + kx sits at (kx & 1) * PWE + li + (kx >> 1)
+            const int pcol = STRIDE == 1 ? li + kx : (kx & 1) * PWE + li + (kx >> 1);
+            const _Float16* src = sB + (lh * 2) * BPLANE + (((wn * TN + b) * STRIDE + ky) * PW + pcol) * 8;
             f.bh[b] = *reinterpret_cast<const v8h*>(src);
             f.bl[b] = *reinterpret_cast<const v8h*>(src + BPLANE);
         }
@@ -443,20 +448,20 @@ conv2d_pack_f16x3_kernel(const float* w, const float* outScale, float* wp, int O
     }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int STRIDE, int WM, int WN, int TM, int TN>
 static int launch_plain_f16x3(const sg3_conv2d_params& q, hipStream_t st) {
     constexpr int BM = WM * TM * 32, ROWS = WN * TN;
-    constexpr size_t ldsBytes = ((size_t)BM * (9 * 32 + 8) + 4 * (size_t)(ROWS + 2) * 34 * 8) * sizeof(_Float16);
+    constexpr size_t ldsBytes = ((size_t)BM * (9 * 32 + 8) + 4 * (size_t)((ROWS - 1) * STRIDE + 3) * (31 * STRIDE + 3) * 8) * sizeof(_Float16);
     PlainConvParams p;
     p.x = q.x; p.wp = q.wPacked; p.inScale = q.inScale; p.inShift = q.inShift; p.bias = q.bias; p.slope = q.slope; p.out = q.out;
-    p.N = q.N; p.I = q.I; p.O = q.O; p.H = q.H; p.W = q.W; p.stride = 1; p.pad = q.pad; p.act = q.act;
-    p.outH = q.H + 2 * q.pad - 2; p.outW = q.W + 2 * q.pad - 2;
+    p.N = q.N; p.I = q.I; p.O = q.O; p.H = q.H; p.W = q.W; p.stride = STRIDE; p.pad = q.pad; p.act = q.act;
+    p.outH = (q.H + 2 * q.pad - 3) / STRIDE + 1; p.outW = (q.W + 2 * q.pad - 3) / STRIDE + 1;
     p.nch = ceil_div(q.I, 16);
     p.xTiles = ceil_div(p.outW, 32); p.yTiles = ceil_div(p.outH, ROWS); p.mTiles = ceil_div(q.O, BM);
     const long long total = (long long)p.xTiles * p.yTiles * p.mTiles * q.N;
     if (total > 0x7fffffffLL) { set_error("conv2d: grid too large"); return SG3_BAD_ARG; }
     p.totalBlocks = (int)total;
-    auto kern = conv2d_f16x3_kernel<WM, WN, TM, TN>;
+    auto kern = conv2d_f16x3_kernel<STRIDE, WM, WN, TM, TN>;
     if (ldsBytes > 64 * 1024)
         SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), ldsBytes, st, p, q.rangeFlag);
@@ -465,9 +470,10 @@ static int launch_plain_f16x3(const sg3_conv2d_params& q, hipStream_t st) {
 }
 
 static int dispatch_plain_f16x3(const sg3_conv2d_params& q, hipStream_t st) {
+    if (q.stride == 2) return launch_plain_f16x3<2, 1, 4, 2, 1>(q, st);           // 64 x (4 rows x 32), 9 x 65 patch
     const int outH = q.H + 2 * q.pad - 2;
-    if (outH <= 16) return launch_plain_f16x3<1, 4, 2, 1>(q, st);                 // 64 x (4 rows x 32): the 16x16 maps
-    return launch_plain_f16x3<1, 4, 2, 2>(q, st);                                 // 64 x (8 rows x 32)
+    if (outH <= 16) return launch_plain_f16x3<1, 1, 4, 2, 1>(q, st);              // 64 x (4 rows x 32): the 16x16 maps
+    return launch_plain_f16x3<1, 1, 4, 2, 2>(q, st);                              // 64 x (8 rows x 32)
 }
 
 template <int KS, int STRIDE, int WM, int WN, int TM, int TN>
@@ -527,7 +533,7 @@ int sg3_conv2d(const sg3_conv2d_params* p, void* stream) {
     SG3_REQUIRE(p->H + 2 * p->pad >= p->k && p->W + 2 * p->pad >= p->k, "conv2d: empty output");
     hipStream_t st = (hipStream_t)stream;
     if (p->precision == SG3_CONV_F16X3) {
-        SG3_REQUIRE(p->k == 3 && p->stride == 1 && p->rangeFlag, "conv2d: the f16x3 form takes 3x3 stride-1 kernels and a range flag");
+        SG3_REQUIRE(p->k == 3 && p->rangeFlag, "conv2d: the f16x3 form takes 3x3 kernels and a range flag");
         SG3_REQUIRE((int64_t)p->I * p->H * p->W * 4 < (int64_t)1 << 31, "conv2d: f16x3 needs a sample below 2 GiB (32-bit offsets)");
         return dispatch_plain_f16x3(*p, st);
     }
