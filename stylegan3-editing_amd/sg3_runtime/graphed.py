@@ -83,3 +83,61 @@ class GraphedSynthesis:
             self.static_ws.copy_(ws, non_blocking=True)
         self.graph.replay()
         return self.static_out
+
+
+class GraphedReStyleStep:
+    """ONE ReStyle refinement step -- cat(frames, previous output) -> encoder -> + previous latent -> synthesis under the
+    identity transform -> face_pool -- captured as a hipGraph for a fixed batch (reference models/setgan/encoder/psp3.py:45-70
+    inside utils/inference_utils.py:74-108).  Step 0 is the same graph fed with the average image and `latent_avg`
+    (psp3.py:58-60: `codes + latent_avg.repeat(N,1,1)` is the same sum).  An eager step is ~330 launches (150 encoder, 75
+    decoder, ~100 small torch ops between them); the replay removes their gaps and all Python between them.
+
+    The encoder's split-precision range guard needs a host read (plain_conv.overflowed), which cannot sit inside a graph: the
+    caller resets the flag before the loop and reads it once after it (`run_on_batch` does, and repeats the batch eagerly --
+    where the fp32 fallback lives -- if it was raised).  Weight changes after capture raise at the next replay, like
+    GraphedSynthesis."""
+
+    def __init__(self, net, batch, warmup=2):
+        self.net, self.batch = net, int(batch)
+        dev = next(net.parameters()).device
+        assert dev.type == 'cuda', 'GraphedReStyleStep needs the network on a GPU'
+        self.device = dev
+        G = net.decoder
+        self.frames = torch.zeros([self.batch, 3, 256, 256], device=dev)
+        self.prev_image = torch.zeros([self.batch, 3, 256, 256], device=dev)
+        self.prev_latent = torch.zeros([self.batch, int(net.n_styles), int(G.w_dim)], device=dev)
+        self.identity = torch.eye(3, device=dev).repeat(self.batch, 1, 1)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+            self.image, self.latent, self.pooled = self._eager()
+        self._fingerprint = self._weights_fingerprint()
+
+    def _weights_fingerprint(self):
+        G = self.net.decoder
+        tensors = list(self.net.encoder.parameters()) + list(self.net.encoder.buffers()) + list(G.synthesis.parameters()) + list(G.synthesis.buffers())
+        return tuple((t.data_ptr(), t._version) for t in tensors if t is not self.identity and t is not G.synthesis.input.transform)
+
+    def _eager(self):
+        net = self.net
+        codes = net.encoder._forward_kernels(torch.cat([self.frames, self.prev_image], dim=1)) + self.prev_latent
+        net.decoder.synthesis.input.transform = self.identity
+        image = net.decoder.synthesis(codes, noise_mode='const', force_fp32=True)
+        return image, codes, net.face_pool(image)
+
+    def __call__(self, frames, prev_image, prev_latent):
+        """Returns (image [B,3,R,R], latent [B,n_styles,512], image pooled to 256^2): static tensors, overwritten by the next replay."""
+        if self._weights_fingerprint() != self._fingerprint:
+            raise RuntimeError('GraphedReStyleStep: encoder / generator weights changed since capture; build a new one')
+        self.frames.copy_(frames, non_blocking=True)
+        self.prev_image.copy_(prev_image, non_blocking=True)
+        self.prev_latent.copy_(prev_latent.expand_as(self.prev_latent), non_blocking=True)
+        self.net.decoder.synthesis.input.transform = self.identity
+        self.graph.replay()
+        return self.image, self.latent, self.pooled

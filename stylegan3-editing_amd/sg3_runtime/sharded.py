@@ -56,13 +56,24 @@ class ShardedInversion:
     batch_size : frames per run_on_batch call on each rank
     """
 
-    def __init__(self, net, opts, batch_size=16):
+    def __init__(self, net, opts, batch_size=16, use_graph=True):
         from utils.inference_utils import get_average_image
         self.net, self.opts, self.batch_size = net, opts, int(batch_size)
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         with torch.no_grad():
             self.avg_image = get_average_image(net)
+        # full batches replay one captured ReStyle step (encoder + decoder + pooling); ragged last batches run eagerly
+        device = next(net.parameters()).device
+        if use_graph and device.type == 'cuda' and not getattr(opts, 'resize_outputs', False):
+            from .graphed import GraphedReStyleStep
+            have = getattr(net, 'graphed_step', None)
+            if have is None or have.batch != self.batch_size:
+                try:
+                    net.graphed_step = GraphedReStyleStep(net, self.batch_size)
+                except RuntimeError as err:                      # capture refused: the eager loop is always there
+                    print(f'[ShardedInversion] hipGraph capture of the ReStyle step failed, running eagerly: {err}')
+                    net.graphed_step = None
 
     def invert(self, frames, landmarks_transforms=None):
         """frames: [F,3,256,256] tensor (or any indexable returning such slices) holding ALL frames; every rank reads only

@@ -42,6 +42,12 @@ def run_on_batch(inputs, net, opts, avg_image, landmarks_transform=None):
     y_hat, latent = None, None
     step_latents = []
     resize_outputs = getattr(opts, 'resize_outputs', False)
+    graphed = getattr(net, 'graphed_step', None)
+    if (graphed is not None and inputs.is_cuda and inputs.shape[0] == graphed.batch and not resize_outputs and not torch.is_grad_enabled()
+            and not net.training):
+        done = _run_on_batch_graphed(inputs, net, opts, avg_image, landmarks_transform, graphed)
+        if done is not None:
+            return done
     for it in range(opts.n_iters_per_batch):
         if it == 0:
             x_input = torch.cat([inputs, avg_image.unsqueeze(0).repeat(inputs.shape[0], 1, 1, 1)], dim=1)
@@ -65,4 +71,32 @@ def run_on_batch(inputs, net, opts, avg_image, landmarks_transform=None):
     all_latents = torch.stack(step_latents).cpu().numpy()               # [steps, N, 16, 512]
     for idx in range(inputs.shape[0]):
         results_latent[idx] = [all_latents[it, idx] for it in range(len(step_latents))]
+    return results_batch, results_latent
+
+
+def _run_on_batch_graphed(inputs, net, opts, avg_image, landmarks_transform, graphed):
+    """The same loop with every step replayed from ONE captured hipGraph (sg3_runtime.GraphedReStyleStep): step 0 is the graph
+    fed with the average image and latent_avg.  With landmark transforms the last step adds the unaligned render eagerly
+    (inference_utils.py:96-100 returns it instead of the aligned one).  Returns None when the encoder's split-precision range
+    guard fired: the caller then runs the eager loop, which owns the fp32 fallback."""
+    from torch_utils.ops import plain_conv
+    n, steps = inputs.shape[0], opts.n_iters_per_batch
+    plain_conv.reset_overflow(inputs.device)
+    prev_image = avg_image.unsqueeze(0).expand(n, -1, -1, -1)
+    prev_latent = net.latent_avg.to(inputs.device)
+    images, latents = [], []
+    for it in range(steps):
+        image, latent, pooled = graphed(inputs, prev_image, prev_latent)
+        if landmarks_transform is not None and it == steps - 1:
+            y_hat = net._render(latent, landmarks_transform.float(), False)
+        else:
+            y_hat = image.clone()                    # the graph's output buffers are overwritten by the next replay
+        images.append(y_hat)
+        latents.append(latent.clone())
+        prev_image, prev_latent = pooled, latent
+    if plain_conv.overflowed(inputs.device):
+        return None
+    all_latents = torch.stack(latents).cpu().numpy()
+    results_batch = {idx: [images[it][idx] for it in range(steps)] for idx in range(n)}
+    results_latent = {idx: [all_latents[it, idx] for it in range(steps)] for idx in range(n)}
     return results_batch, results_latent

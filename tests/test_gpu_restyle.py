@@ -89,3 +89,25 @@ def test_restyle_full_size_first_step_and_batch_independence():
                 tol = 2e-4 * max(1.0, float(np.abs(lats1[0][it]).max()))
                 assert maxabs(lats[i][it], lats1[0][it]) <= tol, (i, it, maxabs(lats[i][it], lats1[0][it]))
             assert maxabs(imgs[i][4].cpu().numpy(), imgs1[0][4].cpu().numpy()) <= 1e-4, i
+
+
+def test_graphed_restyle_step_equals_eager_loop():
+    """The hipGraph-replayed ReStyle loop (sg3_runtime.GraphedReStyleStep through run_on_batch) against the eager loop: same
+    latents and images, with and without landmark transforms, and eager fallback for a batch the graph was not captured for."""
+    from sg3_runtime import GraphedReStyleStep
+    from utils.inference_utils import get_average_image, run_on_batch
+    net, opts, *_ = build_restyle_pair('Rmini', device=DEV, n_iters=4)
+    x = torch.from_numpy(_frames(3, seed=6)).to(DEV)
+    lt = torch.from_numpy(_landmarks(3)).to(DEV)
+    with torch.no_grad():
+        avg = get_average_image(net)
+        eager = {key: run_on_batch(x, net, opts, avg, landmarks_transform=t) for key, t in (('off', None), ('on', lt))}
+        net.graphed_step = GraphedReStyleStep(net, 3)
+        for key, t in (('off', None), ('on', lt)):
+            imgs, lats = run_on_batch(x, net, opts, avg, landmarks_transform=t)
+            for i in range(3):
+                for it in range(4):
+                    assert maxabs(lats[i][it], eager[key][1][i][it]) <= 1e-5 * max(1.0, float(np.abs(eager[key][1][i][it]).max())), (key, i, it)
+                    assert maxabs(imgs[i][it].cpu().numpy(), eager[key][0][i][it].cpu().numpy()) <= 1e-5, (key, i, it)
+        imgs2, lats2 = run_on_batch(x[:2], net, opts, avg)              # other batch size: eager path
+        assert maxabs(lats2[1][3], eager['off'][1][1][3]) <= 1e-4 * max(1.0, float(np.abs(lats2[1][3]).max()))
