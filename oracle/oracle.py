@@ -544,12 +544,13 @@ def adaptive_avg_pool(x, out_hw=(256, 256)):
     return np.stack([rows[:, :, :, a:b].mean(axis=3) for a, b in bins(w, ow)], axis=3).astype(np.float32)
 
 
-def psp_forward(enc_sd, gen_sd, sched, x, latent=None, latent_avg=None, resize=True, input_code=False, landmarks_transform=None):
-    """models/setgan/encoder/psp3.py:45-84.  Returns (aligned images, unaligned images or None, codes)."""
+def psp_forward(enc_sd, gen_sd, sched, x, latent=None, latent_avg=None, resize=True, input_code=False, landmarks_transform=None, encoder=None):
+    """models/setgan/encoder/psp3.py:45-84.  Returns (aligned images, unaligned images or None, codes).  `encoder` (a callable
+    x -> codes) replaces the IR-SE50 backbone built from `enc_sd` (the loop fixtures use a small stand-in encoder)."""
     if input_code:
         codes = x.astype(np.float32)
     else:
-        codes = backbone_encoder(enc_sd, x)
+        codes = backbone_encoder(enc_sd, x) if encoder is None else np.asarray(encoder(x), dtype=np.float32)
         if x.shape[1] == 6 and latent is not None:
             codes = codes + latent                                          # :56-58 residual step
         else:
@@ -573,7 +574,7 @@ def get_average_image(enc_sd, gen_sd, sched, latent_avg):
     return psp_forward(enc_sd, gen_sd, sched, x, input_code=True)[0][0]
 
 
-def run_on_batch(enc_sd, gen_sd, sched, inputs, latent_avg, avg_image, n_iters, landmarks_transform=None, resize_outputs=False):
+def run_on_batch(enc_sd, gen_sd, sched, inputs, latent_avg, avg_image, n_iters, landmarks_transform=None, resize_outputs=False, encoder=None):
     """utils/inference_utils.py:67-111.  Returns (per-step output images [steps][N,3,H,W], per-step latents [steps][N,16,512],
     the ALIGNED image of the last step).  With transforms the reference's last entry is the unaligned image (:96-100); every
     other quantity is the same with and without them, so one call pins both forms."""
@@ -583,7 +584,7 @@ def run_on_batch(enc_sd, gen_sd, sched, inputs, latent_avg, avg_image, n_iters, 
         second = np.repeat(avg_image[None], inputs.shape[0], axis=0) if it == 0 else y_hat          # :76-80
         x_input = np.concatenate([inputs, second], axis=1).astype(np.float32)
         aligned, unaligned, latent = psp_forward(enc_sd, gen_sd, sched, x_input, latent=latent, latent_avg=latent_avg,
-                                                 resize=resize_outputs, landmarks_transform=landmarks_transform)
+                                                 resize=resize_outputs, landmarks_transform=landmarks_transform, encoder=encoder)
         # :92-100: aligned output, except that the LAST step returns the unaligned one when transforms are given
         y_hat = unaligned if (landmarks_transform is not None and it == n_iters - 1) else aligned
         step_images.append(y_hat)

@@ -282,7 +282,7 @@ struct Stream {
     template <int S>
     static __device__ __forceinline__ void step(State& st, const StreamParams& p, const T* __restrict__ plane, T* __restrict__ oplane,
                                                 unsigned char* __restrict__ splane, lds_f* sIn, lds_f* sOut, int i, int delta, int lane,
-                                                int oy0, int oy1, int ox0, int oxN, bool pairStore, bool& poison) {
+                                                int oy0, int oy1, int ox0, int oxN, bool pairStore, unsigned long long& poison) {
         constexpr bool RDOWN = RADIAL == 1 || RADIAL == 2 || RADIAL >= 5;   // full 12x12 DOWN filter (config R forward)
         constexpr bool FOLD = RADIAL >= 5;                         // ... whose rows read the same in both directions
         constexpr bool UP2D = RADIAL == 3 || RADIAL == 4;          // full 12x12 UP filter (adjoint of those layers)
@@ -291,17 +291,21 @@ struct Stream {
         constexpr int PS = S % SG3_PREFETCH_ROWS;        // prefetch slot of this row
 #pragma unroll
         for (int q = 0; q < Cfg::NL; q++) sIn[lane + 64 * q] = st.pre[PS][q];
-        // Non-finite input: v_med3 returns the MINIMUM of its operands when one is a NaN, so the fast clamp below would turn a NaN
-        // activation into -clamp, while the reference's `if (fabsf(v) > clamp) v = copysign(clamp, v)` (filtered_lrelu.cu:412-419)
-        // lets it through.  Every sample a lane stages is classified (v_cmp_class: NaN or infinity -- an infinity meets taps of both
-        // signs and becomes a NaN in the filter); the results are OR-ed on the scalar unit, and once any lane of the wave has seen
-        // one the wave takes the exact clamp for the rest of its strip (wave-uniform branch).  The last load of a row holds the
-        // strip's 6 halo samples, which the neighbouring strip stages (and classifies) as its own first samples: it is left out
-        // here, so a NaN is never lost from the image, only its footprint may end 3 columns early at a strip seam.
+        // Non-finite input.  v_med3 returns the MINIMUM of its operands when one is a NaN, so the clamp below turns a NaN activation
+        // into -clamp, while the reference's `if (fabsf(v) > clamp) v = copysign(clamp, v)` (filtered_lrelu.cu:412-419) lets it
+        // through; a NaN-preserving clamp costs an instruction per upsampled sample (8 %), and a wave-uniform branch to one cost 5 %
+        // (measured: it fences the scheduler).  Instead every sample a lane stages is classified (one v_cmp_class per load: NaN or
+        // infinity, which meets taps of both signs in the filter), the lane masks are OR-ed on the scalar unit, and from the row a
+        // wave has met one on, its output gain is NaN: every output it still writes in this strip is NaN.  That is a superset of the
+        // reference's NaN footprint (a failure stays loud and stays where it happened), at no cost inside the nonlinearity.  The
+        // last load of a row holds the strip's 6 halo samples, which the neighbouring strip classifies as its own: left out here.
         if (SIGNS == 0 && SG3_NAN_GUARD) {
 #pragma unroll
-            for (int q = 0; q < Cfg::NL - 1; q++)
-                poison = poison || (__builtin_amdgcn_ballot_w64(__builtin_amdgcn_class(st.pre[PS][q], 0x207)) != 0ull);
+            for (int q = 0; q < Cfg::NL - 1; q++) {
+                unsigned long long m;            // asm: the file is built with -fno-honor-nans, which folds the NaN classes away
+                asm("v_cmp_class_f32 %0, %1, %2" : "=s"(m) : "v"(st.pre[PS][q]), "s"(0x207));
+                poison |= m;
+            }
         }
         unsigned sgNow[U];               // this row's sign bytes: the prefetch below reuses their slot
 #pragma unroll
@@ -336,7 +340,8 @@ struct Stream {
         // ---- U new upsampled rows ----
         const float slope = p.slope, clampv = p.clamp / p.gain, gain = p.gain;
         // sign-write mode applies the gain before the nonlinearity; the 2-D up filter's taps carry no up^2 factor
-        const float gainOut = (SIGNS == 1) ? 1.f : (UP2D ? p.gain * (float)(U * U) : p.gain);
+        const float gainOut = (SIGNS == 1) ? 1.f : (UP2D ? p.gain * (float)(U * U) :
+                              ((SIGNS == 0 && SG3_NAN_GUARD && poison != 0ull) ? __builtin_bit_cast(float, 0x7fc00000u) : p.gain));
 #pragma unroll
         for (int j = 0; j < U; j++) {
             const int kv = U - 1 - j;                          // vertical up phase of this row
@@ -429,19 +434,8 @@ struct Stream {
                 // down filter instead of once per upsampled sample (clampv = clamp / gain here)
                 const v2f s0 = u0 * splat(slope), s1 = u1 * splat(slope);
                 a[0] = __builtin_fmaxf(u0.x, s0.x); a[1] = __builtin_fmaxf(u0.y, s0.y); a[2] = __builtin_fmaxf(u1.x, s1.x); a[3] = __builtin_fmaxf(u1.y, s1.y);
-                if (SG3_NAN_GUARD && __builtin_expect(poison, 0)) {
-                    // exact form on the bit patterns: magnitudes above the clamp up to and including infinity are clamped, NaNs
-                    // (magnitude bits beyond infinity's) pass
-                    const unsigned cb = __builtin_bit_cast(unsigned, clampv);
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const unsigned bits = __builtin_bit_cast(unsigned, a[c]), mag = bits & 0x7fffffffu;
-                        a[c] = (mag > cb && mag <= 0x7f800000u) ? __builtin_bit_cast(float, cb | (bits & 0x80000000u)) : a[c];
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; c++) a[c] = __builtin_amdgcn_fmed3f(a[c], -clampv, clampv);
-                }
+                for (int c = 0; c < 4; c++) a[c] = __builtin_amdgcn_fmed3f(a[c], -clampv, clampv);
             }
             const v2f r0 = {a[0], a[1]}, r1 = {a[2], a[3]};
             const int kp = (VPH + S * U + j) % D;              // down phase of this row (a trip starts at phase VPH)
@@ -658,7 +652,7 @@ struct Stream {
         }
 
         st.osum = 0.f;
-        bool poison = false;
+        unsigned long long poison = 0ull;         // lanes that have staged a non-finite sample so far (wave-uniform, scalar registers)
         if (SIGNS) {
             const int c0 = uxs + p.sx;                           // sign-tensor column of lane 0's first upsampled column
             st.sq = to_sgpr_i(((c0 % 4) + 4) % 4);

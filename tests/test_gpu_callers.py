@@ -112,3 +112,38 @@ def test_styleclip_sweep_batch32_equals_single_renders():
             single = G.synthesis(None, all_s={c: v[i:i + 1] for c, v in sweep.items()}, noise_mode='const', force_fp32=True)
             assert maxabs(batched[i:i + 1].cpu().numpy(), single.cpu().numpy()) <= 1e-5, i
         assert maxabs(batched[0].cpu().numpy(), batched[54].cpu().numpy()) > 1e-3
+
+
+@pytest.mark.parametrize('cfg', ['Ttiny', 'Rtiny'])
+def test_callers_match_reference_fixtures(cfg):
+    """FOV Expander and the StyleCLIP sweep on the HIP path against the outputs of the reference's own Expander / edit_image
+    (tests/golden/callers.npz); the video post-processing frames likewise (config T)."""
+    from callers_common import styleclip_case
+    from editing.styleclip_global_directions.edit import edit_image
+    from editing.styleclip_global_directions.global_direction import StyleCLIPGlobalDirection
+    from helpers import golden
+    from inversion.video import post_processing as pp
+    from utils.fov_expansion import Expander
+    g = golden('callers')
+    G = build_product_generator(cfg, device=DEV)
+    ws = synth_ws(2, G.num_ws, G.w_dim, seed=4)
+    got = Expander(G, force_fp32=True).generate_expanded_image(ws=torch.from_numpy(ws).to(DEV), landmark_t=landmark(), pixels_right=8, pixels_left=4, pixels_top=6, pixels_bottom=0)
+    assert maxabs(got.cpu().numpy(), g[f'fov/{cfg}/img']) <= 1e-4
+    lat = synth_ws(1, G.num_ws, G.w_dim, seed=12)[0]
+    G.synthesis.input.transform = torch.eye(3, device=DEV)
+    with torch.no_grad():
+        s_avg = G.synthesis.W2S(G.mapping.w_avg.unsqueeze(0).repeat(1, G.num_ws, 1))
+    delta_i_c, delta_i, s_std = styleclip_case(s_avg)
+    calc = StyleCLIPGlobalDirection(torch.from_numpy(delta_i_c).to(DEV), {k: torch.from_numpy(v).to(DEV) for k, v in s_std.items()}, ['{}'], s_avg)
+    calc.get_delta_i = lambda prompts: torch.from_numpy(delta_i).to(DEV)
+    results, _ = edit_image(lat, landmark().astype(np.float32), G, calc, sweep_opts(), max_batch=4, force_fp32=True)
+    assert maxabs(results.cpu().numpy(), g[f'styleclip/{cfg}/results']) <= 1e-4
+    if cfg == 'Ttiny':
+        lat7 = synth_ws(7, G.num_ws, G.w_dim, seed=9)
+        from oracle import oracle as O
+        tr = [torch.from_numpy(np.linalg.inv(O.make_transform((0.02 * i, -0.01 * i), 2.0 * i))) for i in range(7)]
+        results7 = {'result_latents': {f'{i:04d}': lat7[i] for i in range(7)}, 'landmarks_transforms': tr}
+        vopts = types.SimpleNamespace(expansion_amounts=[4, 2, 0, 3], landmarks_transforms_path='given')
+        frames = pp.postprocess_and_smooth_inversions(results7, types.SimpleNamespace(decoder=G), vopts, frames_per_batch=2, force_fp32=True)
+        for f, w in zip(frames, g['video/frames']):
+            assert np.abs(f.astype(np.int32) - w.astype(np.int32)).max() <= 1

@@ -111,3 +111,15 @@ def test_graphed_restyle_step_equals_eager_loop():
                     assert maxabs(imgs[i][it].cpu().numpy(), eager[key][0][i][it].cpu().numpy()) <= 1e-5, (key, i, it)
         imgs2, lats2 = run_on_batch(x[:2], net, opts, avg)              # other batch size: eager path
         assert maxabs(lats2[1][3], eager['off'][1][1][3]) <= 1e-4 * max(1.0, float(np.abs(lats2[1][3]).max()))
+
+
+@pytest.mark.parametrize('cfg', ['Tmini', 'Rmini'])
+def test_psp_forward_and_restyle_loop_match_reference_fixture(cfg):
+    """pSp.forward and run_on_batch on the HIP path against the fixture the REFERENCE's own psp3.forward / run_on_batch produced
+    (tests/golden/make_golden_callers.py): latent_avg on step 0, residual steps, landmark transforms, face_pool."""
+    from test_callers_golden_cpu import build_loop_net, check_loop_against_golden
+    from torch_utils import _sg3abi
+    net, opts = build_loop_net(cfg, device=DEV)
+    n0 = _sg3abi.launch_count
+    check_loop_against_golden(net, opts, cfg, DEV, tol_img=1e-4, tol_lat=1e-5)
+    assert _sg3abi.launch_count - n0 > 300, 'the decoder did not run on the HIP kernels'
