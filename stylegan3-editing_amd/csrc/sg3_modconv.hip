@@ -25,6 +25,7 @@
 // demodulation (dcoef) is applied in the epilogue; bias/activation belong to the following filtered_lrelu.
 #include "sg3_common.h"
 #include "sg3_split.h"
+#include <cstdlib>
 
 #ifndef SG3_TAILPACK
 #define SG3_TAILPACK 1          // 0 compiles the tap-packed tail chunk of the 3x3 kernel out (A/B builds)
@@ -498,7 +499,12 @@ modconv_f16x3_kernel(ConvParams p) {
 // LDS per buffer: A rows of (hi16|lo16) x 2 halfs + 8 halfs of padding; B as planes [k-step][channel-half][hi|lo][pixel][8].
 // NBUF = 1: one LDS image (two barriers per stage) so that TWO workgroups fit a CU -- for the thin layers, whose few K
 // stages leave a lone workgroup waiting on HBM at the start and the end of every tile.
-template <typename T, int WM, int WN, int TM, int TN, bool SPLIT, int NBUF>
+// M16: the matrix instruction is v_mfma_f32_16x16x32_f16 (one per 16 x 16 output block and 32-channel stage) instead of
+// v_mfma_f32_32x32x16_f16 (two per 32 x 32 block): the same cycles per FLOP and the same LDS fragment bytes, but the chip holds
+// a 15 % higher clock on the small shape (profiles/r02_mfma_shape.txt).  A fragment = 16 rows x 32 channels: lane l holds row
+// l % 16, channels 8g .. 8g+7 with g = l / 16 = (k-step, channel-half) of the staged image; B likewise for 16 pixels; the
+// accumulator block holds rows 4 (l / 16) + i, pixel l % 16.
+template <typename T, int WM, int WN, int TM, int TN, bool SPLIT, int NBUF, bool M16>
 __global__ void __launch_bounds__(512, NBUF == 1 ? 4 : 2)      // second argument: waves per SIMD (a workgroup is two per SIMD)
 modconv1_f16x3_kernel(ConvParams p) {
     constexpr int KSUB = 2, KC = 16 * KSUB;
@@ -558,13 +564,14 @@ modconv1_f16x3_kernel(ConvParams p) {
     const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.sIn + (size_t)n * p.I), (short)0, p.I * 4, 0x00020000);
     float rsc;
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[TM][TN];                                // M16: the same 16 registers per 32 x 32 block, viewed as 2 x 2 blocks of 4
 #pragma unroll
     for (int a = 0; a < TM; a++)
 #pragma unroll
         for (int b = 0; b < TN; b++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+    const int l16 = lane & 15, lg = lane >> 4;         // M16: row / pixel inside a 16-block, k group (k-step = lg >> 1, channel-half = lg & 1)
 
     u32x4 ra[A_PER];
     typename bufld<T>::raw2 rb[8];                     // raw pixel pairs, one per channel (unpacked in stage)
@@ -639,6 +646,44 @@ modconv1_f16x3_kernel(ConvParams p) {
             }
     };
 
+    // M16: one stage (32 channels) = one K step.  Fragments of one 16-row block of A at a time (its 2 TN x 2 B fragments are
+    // loaded once per stage and kept): 3 products per 16 x 16 block, the same order (lo*hi, hi*lo, hi*hi) as the 32-wide form.
+    auto stage_m16 = [&](const _Float16* buf) {
+        const _Float16* sA = buf;
+        const _Float16* sB = buf + BM * AS;
+        v8h bh[TN][2], bl[TN][2];
+#pragma unroll
+        for (int b = 0; b < TN; b++)
+#pragma unroll
+            for (int pb = 0; pb < 2; pb++) {
+                const _Float16* src = sB + (lg * NPART) * BPLANE + ((wn * TN + b) * 32 + pb * 16 + l16) * 8;
+                bh[b][pb] = *reinterpret_cast<const v8h*>(src);
+                if (SPLIT) bl[b][pb] = *reinterpret_cast<const v8h*>(src + BPLANE);
+            }
+#pragma unroll
+        for (int a = 0; a < TM; a++)
+#pragma unroll
+            for (int rb_ = 0; rb_ < 2; rb_++) {
+                const _Float16* src = sA + ((wm * TM + a) * 32 + rb_ * 16 + l16) * AS + (lg >> 1) * 32 + (lg & 1) * 8;
+                const v8h ah = *reinterpret_cast<const v8h*>(src);
+                v8h al;
+                if (SPLIT) al = *reinterpret_cast<const v8h*>(src + 16);
+#pragma unroll
+                for (int b = 0; b < TN; b++)
+#pragma unroll
+                    for (int pb = 0; pb < 2; pb++) {
+                        f32x4 c = {acc[a][b][(rb_ * 2 + pb) * 4], acc[a][b][(rb_ * 2 + pb) * 4 + 1], acc[a][b][(rb_ * 2 + pb) * 4 + 2], acc[a][b][(rb_ * 2 + pb) * 4 + 3]};
+                        if (SPLIT) {
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[b][pb], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[b][pb], c, 0, 0, 0);
+                        }
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[b][pb], c, 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) acc[a][b][(rb_ * 2 + pb) * 4 + i] = c[i];
+                    }
+            }
+    };
+
     fetch(0);
     stage(smh, 0);
     __syncthreads();
@@ -646,7 +691,9 @@ modconv1_f16x3_kernel(ConvParams p) {
         const _Float16* cur = smh + (NBUF == 2 ? (ch & 1) * BUF : 0);
         const bool more = ch + 1 < p.nch;
         if (more) fetch(ch + 1);
-        if (TM * TN <= 4) {
+        if (M16) {
+            stage_m16(cur);
+        } else if (TM * TN <= 4) {
             Frags f0, f1;
             load_frags(f0, cur, 0);
             load_frags(f1, cur, 1);
@@ -671,6 +718,42 @@ modconv1_f16x3_kernel(ConvParams p) {
     }
 
     T* outp = (T*)p.out + (size_t)n * p.O * P;
+    if (M16) {
+        // accumulator register (rb * 2 + pb) * 4 + i of block (a, b): channel (wm TM + a) 32 + rb 16 + 4 lg + i, pixel (wn TN + b) 32 + pb 16 + l16
+        const unsigned planeB16 = (unsigned)P * (unsigned)sizeof(T);
+        const bool desc = (unsigned long long)(p.mTiles * BM + 32) * planeB16 < 0x7fffffffULL;
+        const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)outp, (short)0, desc ? (int)((unsigned)p.O * planeB16) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dcoef + (size_t)n * p.O), (short)0, p.O * 4, 0x00020000);
+#pragma unroll
+        for (int a = 0; a < TM; a++)
+#pragma unroll
+            for (int rb_ = 0; rb_ < 2; rb_++) {
+                const int oL = o0 + (wm * TM + a) * 32 + rb_ * 16 + 4 * lg;
+                float d[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, (oL + i) * 4, 0, 0));
+#pragma unroll
+                for (int b = 0; b < TN; b++)
+#pragma unroll
+                    for (int pb = 0; pb < 2; pb++) {
+                        const int px = p0 + (wn * TN + b) * 32 + pb * 16 + l16;
+                        if (desc) {
+                            const unsigned base = px < P ? (unsigned)oL * planeB16 + (unsigned)px * (unsigned)sizeof(T) : 0x80000000u;
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                const float v = acc[a][b][(rb_ * 2 + pb) * 4 + i] * d[i];
+                                if (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orr, (int)(base + (unsigned)i * planeB16), 0, 0);
+                                else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), orr, (int)(base + (unsigned)i * planeB16), 0, 0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; i++)
+                                if (oL + i < p.O && px < P) io<T>::st(outp + (size_t)(oL + i) * P + px, acc[a][b][(rb_ * 2 + pb) * 4 + i] * d[i]);
+                        }
+                    }
+            }
+        return;
+    }
     const unsigned planeB = (unsigned)P * (unsigned)sizeof(T);
     // every offset a lane can form -- channels of the padded last M tile included -- must stay below 2^31, so that nothing
     // wraps around into the tensor: (padded O + one wave block) * plane < 2^31
@@ -1017,6 +1100,12 @@ static int dispatch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     return pack ? launch_conv_f16x3<T, 2, 2, 4, SPLIT, true>(q, st) : launch_conv_f16x3<T, 2, 2, 4, SPLIT, false>(q, st);   //  64 x (8 rows x 32)
 }
 
+// SG3_CONV1_MFMA32=1 in the environment selects the 32x32x16 form of the 1x1 kernels (A/B timing; read once)
+static bool conv1_use_m16() {
+    static const bool v = [] { const char* e = getenv("SG3_CONV1_MFMA32"); return !(e && e[0] == '1'); }();
+    return v;
+}
+
 template <typename T, int WM, int WN, int TM, int TN, bool SPLIT, int NBUF = 2>
 static int launch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     constexpr int BM = WM * TM * 32, ROWS = WN * TN;
@@ -1030,7 +1119,10 @@ static int launch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     const long long total = (long long)p.xTiles * p.yTiles * p.mTiles * q.N;
     if (total > 0x7fffffffLL) { set_error("modulated_conv2d: grid too large"); return SG3_BAD_ARG; }
     p.totalBlocks = (int)total;
-    auto kern = modconv1_f16x3_kernel<T, WM, WN, TM, TN, SPLIT, NBUF>;
+    // the 16x16x32 form for the compute-bound tiles (R-1024, batch 8: 28.4 vs 32.2 ms over the 1024 .. 406-channel layers); the
+    // thin HBM-bound layers keep 32x32x16: its stores are 128-byte row segments, the 16-wide blocks' 64-byte ones cost them 5 %
+    const bool m16 = NBUF == 2 && conv1_use_m16();
+    auto kern = m16 ? modconv1_f16x3_kernel<T, WM, WN, TM, TN, SPLIT, NBUF, true> : modconv1_f16x3_kernel<T, WM, WN, TM, TN, SPLIT, NBUF, false>;
     if (ldsBytes > 64 * 1024)
         SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), ldsBytes, st, p);

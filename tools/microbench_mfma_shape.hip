@@ -47,6 +47,17 @@ __global__ void __launch_bounds__(256, 2) k(float* out, unsigned long long* stam
 #pragma unroll
                 for (int m = 0; m < 4; m++)
                     acc32[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(m >> 1) * 2 + kh], b[(m & 1) * 2 + kh], acc32[m], 0, 0, 0);
+        } else if (SHAPE == 1616) {
+            // legacy K = 16 instruction on the same 16x16 blocks: two per block and K = 32 step (operands: 4 halfs per lane)
+            typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+                for (int m = 0; m < 16; m++) {
+                    const v4h av = kh ? (v4h){a[m >> 2][4], a[m >> 2][5], a[m >> 2][6], a[m >> 2][7]} : (v4h){a[m >> 2][0], a[m >> 2][1], a[m >> 2][2], a[m >> 2][3]};
+                    const v4h bv = kh ? (v4h){b[m & 3][4], b[m & 3][5], b[m & 3][6], b[m & 3][7]} : (v4h){b[m & 3][0], b[m & 3][1], b[m & 3][2], b[m & 3][3]};
+                    acc16[m] = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, acc16[m], 0, 0, 0);
+                }
         } else {
             // 4 x 4 blocks of 16x16, one K = 32 step: a[rowblock], b[colblock]
 #pragma unroll
@@ -88,7 +99,7 @@ static void run(float* d, unsigned long long* st) {
     for (int i = 0; i < blocks * 4; i++) if (h[2 * i + 1]) ghz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1);
     std::sort(ghz.begin(), ghz.end());
     const double flop = (double)blocks * 4 * iters * 2.0 * 64 * 64 * 32;
-    printf("%s  %-22s %6.3f PFLOP/s  %7.2f ms  clock %.3f GHz  %.1f cycles per K=32 step of a 64x64 tile (ideal 256)\n", SHAPE == 32 ? "32x32x16" : "16x16x32",
+    printf("%-9s %-22s %6.3f PFLOP/s  %7.2f ms  clock %.3f GHz  %.1f cycles per K=32 step of a 64x64 tile (ideal 256)\n", SHAPE == 32 ? "32x32x16" : (SHAPE == 16 ? "16x16x32" : "16x16x16"),
            LDS ? "+ 8 ds_read_b128/step" : "operands in registers", flop / ms * 1e-12, ms, ghz[ghz.size() / 2], ms * 1e-3 * ghz[ghz.size() / 2] * 1e9 / iters / 2.0);
     fflush(stdout);
 }
@@ -97,7 +108,7 @@ int main() {
     float* d; unsigned long long* st;
     (void)hipMalloc(&d, 512 * 256 * 4); (void)hipMalloc(&st, 512 * 4 * 16);
     for (int rep = 0; rep < 2; rep++) {
-        run<32, 0>(d, st); run<16, 0>(d, st); run<32, 1>(d, st); run<16, 1>(d, st);
+        run<32, 0>(d, st); run<16, 0>(d, st); run<1616, 0>(d, st); run<32, 1>(d, st); run<16, 1>(d, st);
     }
     return 0;
 }
