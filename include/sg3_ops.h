@@ -322,6 +322,10 @@ typedef struct sg3_modconv_params {
     const float*   epilogueBias;
     float          epilogueClamp;
     float          epilogueScale;
+    /* Row pitch of `out` in elements; 0 = dense (outW).  The caller may allocate [N,O,outH,pitch] with pitch a multiple of 128
+     * bytes and hand the [..., :outW] view on: a 1046-float row is 4184 bytes, so every 128-byte store segment of a dense output
+     * straddles two cache lines (3x3 split-precision / fp16 kernels only; other forms require 0 or outW). */
+    int32_t        outRowStride;
 } sg3_modconv_params;
 
 SG3_API int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream);

@@ -50,6 +50,7 @@ struct ConvParams {
     int nch;                         // K chunks = ceil(I / KC)
     int xTiles, yTiles, mTiles;
     int totalBlocks;
+    int outPitch;                    // elements between output rows (row-streaming 3x3 kernel; elsewhere = outW)
     int tailPack;                    // row-streaming 3x3 kernel: the last K chunk holds at most 4 channels (see the kernel)
     const float* epBias; float epClamp, epScale;     // ToRGB kernel only: out = clamp(conv + bias[o]) * scale (see sg3_modconv_params)
 };
@@ -448,9 +449,9 @@ modconv_f16x3_kernel(ConvParams p) {
         }
     }
 
-    T* outp = (T*)p.out + (size_t)n * p.O * p.outH * p.outW;
+    T* outp = (T*)p.out + (size_t)n * p.O * p.outH * p.outPitch;
     const int gx = x0 + li;
-    const unsigned planeB = (unsigned)(p.outH * p.outW) * (unsigned)sizeof(T);          // bytes per output channel plane
+    const unsigned planeB = (unsigned)(p.outH * p.outPitch) * (unsigned)sizeof(T);      // bytes per output channel plane
     // every offset a lane can form -- channels of the padded last M tile included -- must stay below 2^31, so that nothing
     // wraps around into the tensor: (padded O + one wave block) * plane < 2^31
     if ((unsigned long long)(p.mTiles * BM + 32) * planeB < 0x7fffffffULL) {
@@ -464,7 +465,7 @@ modconv_f16x3_kernel(ConvParams p) {
         for (int b = 0; b < TN; b++) {
             const int gy = y0 + wn * TN + b;
             if (gy >= p.outH) continue;                                                  // wave-uniform
-            const unsigned rowOff = laneBase + (unsigned)(gy * p.outW) * (unsigned)sizeof(T);
+            const unsigned rowOff = laneBase + (unsigned)(gy * p.outPitch) * (unsigned)sizeof(T);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const unsigned off = rowOff + (unsigned)((r & 3) + 8 * (r >> 2)) * planeB;
@@ -486,7 +487,7 @@ modconv_f16x3_kernel(ConvParams p) {
             for (int b = 0; b < TN; b++) {
                 const int gy = y0 + wn * TN + b;
                 if (gy < p.outH && gx < p.outW)
-                    io<T>::st(outp + ((size_t)o * p.outH + gy) * p.outW + gx, acc[a][b][r] * d);
+                    io<T>::st(outp + ((size_t)o * p.outH + gy) * p.outPitch + gx, acc[a][b][r] * d);
             }
         }
 }
@@ -1066,6 +1067,7 @@ static int launch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     const long long total = (long long)p.xTiles * p.yTiles * p.mTiles * q.N;
     if (total > 0x7fffffffLL) { set_error("modulated_conv2d: grid too large"); return SG3_BAD_ARG; }
     p.totalBlocks = (int)total;
+    p.outPitch = q.outRowStride > 0 ? q.outRowStride : p.outW;
     p.tailPack = PACK ? 1 : 0;
     auto kern = modconv_f16x3_kernel<T, WM, WN, TN, SPLIT, PACK>;
     if (ldsBytes > 64 * 1024)
@@ -1229,6 +1231,12 @@ int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream) {
     SG3_REQUIRE(p->H + 2 * p->pad - p->k + 1 > 0 && p->W + 2 * p->pad - p->k + 1 > 0, "modulated_conv2d: empty output");
     SG3_REQUIRE(p->dtype == SG3_F32 || p->dtype == SG3_F16, "modulated_conv2d: unsupported dtype");
     hipStream_t st = (hipStream_t)stream;
+    {
+        const int outW = p->W + 2 * p->pad - p->k + 1;
+        const bool rowStream = p->k == 3 && (p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16);
+        SG3_REQUIRE(p->outRowStride == 0 || p->outRowStride == outW || (rowStream && p->outRowStride > outW),
+                    "modulated_conv2d: outRowStride must be 0 or outW (a larger pitch is supported by the 3x3 f16x3 / f16 kernels only)");
+    }
     const bool torgb = p->precision == SG3_CONV_FP32 && p->k == 1 && p->pad == 0 && p->O <= 4 && (size_t)p->I * 4 * sizeof(float) <= 48 * 1024;
     SG3_REQUIRE(!p->epilogueBias || torgb, "modulated_conv2d: the bias / clamp / scale epilogue exists for the ToRGB kernel only (1x1, O <= 4, fp32 form)");
     if (p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16) {

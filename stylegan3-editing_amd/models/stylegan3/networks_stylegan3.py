@@ -51,14 +51,14 @@ def _summary(module, *rows):
 
 
 @misc.profiled_function
-def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, x_bound=None, prepared=None, epilogue=None):
+def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, x_bound=None, prepared=None, epilogue=None, align_rows=False):
     """x [N,I,H,W], w [O,I,kh,kw], s [N,I], input_gain [] | [I] | [N,I]  ->  [N,O,H',W'].
 
     Equals a per-sample convolution with weights  w * s[n] (unit-normalised and demodulated when `demodulate`) times
     `input_gain` (reference :24-63).  `x_bound` is an extension: a guaranteed bound on |x| that lets the HIP kernel use
     its split-precision matrix-core path (torch_utils/ops/modulated_conv.py)."""
     return _modconv.modulated_conv2d(x, w, s, demodulate=demodulate, padding=padding, input_gain=input_gain, x_bound=x_bound,
-                                     prepared=prepared, epilogue=epilogue)
+                                     prepared=prepared, epilogue=epilogue, align_rows=align_rows)
 
 
 
@@ -324,7 +324,8 @@ class SynthesisLayer(torch.nn.Module):
             epilogue = (self.bias, self.conv_clamp, 1.0)       # clamp(conv + bias) inside the convolution
         x = modulated_conv2d(x=x.to(dtype), w=self.weight, s=styles, padding=self.conv_kernel - 1,
                              demodulate=(not self.is_torgb), input_gain=input_gain, x_bound=getattr(self, 'input_bound', None),
-                             prepared=prepared, epilogue=epilogue)
+                             prepared=prepared, epilogue=epilogue,
+                             align_rows=(x.is_cuda and not torch.is_grad_enabled()))   # consumed by filtered_lrelu, which honours strides
         if epilogue is not None:
             misc.assert_shape(x, [None, self.out_channels, out_h, out_w])
             return x

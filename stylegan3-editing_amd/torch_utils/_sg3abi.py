@@ -53,7 +53,7 @@ class BiasActParams(ctypes.Structure):
 class ModconvParams(ctypes.Structure):
     _fields_ = [('x', c_vp), ('wPacked', c_vp), ('sIn', c_vp), ('dcoef', c_vp), ('out', c_vp), ('dtype', c_i32),
                 ('N', c_i32), ('I', c_i32), ('O', c_i32), ('H', c_i32), ('W', c_i32), ('k', c_i32), ('pad', c_i32), ('precision', c_i32),
-                ('epilogueBias', c_vp), ('epilogueClamp', c_f32), ('epilogueScale', c_f32)]
+                ('epilogueBias', c_vp), ('epilogueClamp', c_f32), ('epilogueScale', c_f32), ('outRowStride', c_i32)]
 
 
 class FourierParams(ctypes.Structure):

@@ -17,6 +17,7 @@ differentiable torch ops and lets autograd differentiate that composite, so firs
 w.r.t. x, w and s are available.
 """
 import ctypes
+import os
 
 import torch
 
@@ -30,6 +31,8 @@ from .. import misc
 # Calls without a bound always use 'fp32'.  fp16 tensors (the reference's mixed-precision layers) take the plain fp16
 # form: operands rounded to fp16 once, one MFMA per K step, fp32 accumulation -- what an fp16 cuDNN convolution does.
 precision = 'f16x3'
+# `align_rows` requests are honoured unless SG3_CONV_DENSE_ROWS=1 (A/B timing of the padded row pitch)
+_ALIGN_ROWS = os.environ.get('SG3_CONV_DENSE_ROWS', '0') != '1'
 
 
 def _composite(x, w, s, demodulate, padding, input_gain):
@@ -131,12 +134,14 @@ def prepare_batch(specs):
     return plans
 
 
-def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None, x_bound_dev=None, out_scale=None, prepared=None, epilogue=None):
+def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None, x_bound_dev=None, out_scale=None, prepared=None, epilogue=None,
+            align_rows=False):
     """prep + implicit-GEMM kernels.  Returns (out, sIn [N,I], dcoef [N,O] or None): the two per-sample scale vectors are
     what the data-gradient pass needs.  `x_bound_dev`: one-element device tensor holding the bound; `out_scale` [N,O]: extra
     per-sample output-channel scale folded into the epilogue coefficient; `prepared`: the outcome of `prepare_batch` for
     exactly this call (then no prep kernel is launched here); `epilogue` = (bias [O] float32, clamp or None, scale): the ToRGB
-    kernel's fused  clamp(out + bias) * scale  (see `torgb_epilogue_ok`)."""
+    kernel's fused  clamp(out + bias) * scale  (see `torgb_epilogue_ok`); `align_rows`: give the output a row pitch that is a
+    multiple of 128 bytes and return the [..., :outW] view (3x3 split-precision / fp16 kernels: see `sg3_modconv_params.outRowStride`)."""
     n, ci, h, wd = (int(v) for v in x.shape)
     co, ci2, k, _ = (int(v) for v in w.shape)
     if ci != ci2:
@@ -153,7 +158,12 @@ def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None, x_bound_dev=
             pr = _plan(w, s, demodulate, padding, input_gain, x_bound, x_bound_dev, n, h, wd, x.dtype, dev)
             abi.check(lib.sg3_modulated_conv2d_prep(ctypes.byref(pr.params), stream), 'sg3_modulated_conv2d_prep')
         oh, ow = h + 2 * padding - k + 1, wd + 2 * padding - k + 1
-        out = torch.empty([n, co, oh, ow], dtype=x.dtype, device=dev)
+        pitch = ow
+        if align_rows and _ALIGN_ROWS and k == 3 and pr.prec != abi.SG3_CONV_FP32 and ow >= 128:
+            per_line = 128 // x.element_size()
+            pitch = (ow + per_line - 1) // per_line * per_line
+        full = torch.empty([n, co, oh, pitch], dtype=x.dtype, device=dev)
+        out = full if pitch == ow else full[..., :ow]
         coef = pr.dcoef
         if out_scale is not None:
             coef = out_scale.to(torch.float32).contiguous() if pr.dcoef is None else pr.dcoef * out_scale
@@ -162,6 +172,7 @@ def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None, x_bound_dev=
         cp.dtype = abi.dtype_code(x.dtype)
         cp.N, cp.I, cp.O, cp.H, cp.W, cp.k, cp.pad = n, ci, co, h, wd, k, int(padding)
         cp.precision = pr.prec
+        cp.outRowStride = pitch if pitch != ow else 0
         if epilogue is not None:
             bias, clamp, scale = epilogue
             bias = bias.detach().to(device=dev, dtype=torch.float32).contiguous()
@@ -220,8 +231,8 @@ def _weight_gradient(x, dy, k, padding, x_amax=None, dy_amax=None):
 
 class _ModulatedConv2dHip(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, s, input_gain, demodulate, padding, x_bound, prepared=None, epilogue=None):  # pylint: disable=arguments-differ
-        out, s_in, dcoef = _launch(x, w, s, demodulate, padding, input_gain, x_bound, prepared=prepared, epilogue=epilogue)
+    def forward(ctx, x, w, s, input_gain, demodulate, padding, x_bound, prepared=None, epilogue=None, align_rows=False):  # pylint: disable=arguments-differ
+        out, s_in, dcoef = _launch(x, w, s, demodulate, padding, input_gain, x_bound, prepared=prepared, epilogue=epilogue, align_rows=align_rows)
         ctx.save_for_backward(x, w, s, input_gain if input_gain is not None else torch.empty(0), s_in,
                               dcoef if dcoef is not None else torch.empty(0))
         ctx.cfg = (demodulate, padding, input_gain is not None)
@@ -233,7 +244,7 @@ class _ModulatedConv2dHip(torch.autograd.Function):
         x, w, s, g, s_in, dcoef = ctx.saved_tensors
         demodulate, padding, has_gain = ctx.cfg
         need = ctx.needs_input_grad
-        out = [None] * 9
+        out = [None] * 10
         if torch.is_grad_enabled():
             # higher-order gradients: differentiate the reference formulation itself
             ins, idx = [], []
@@ -283,11 +294,14 @@ def torgb_epilogue_ok(w, padding, dtype):
 
 
 @misc.profiled_function
-def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, impl='cuda', x_bound=None, prepared=None, epilogue=None):
+def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, impl='cuda', x_bound=None, prepared=None, epilogue=None,
+                     align_rows=False):
     """x [N,I,H,W], w [O,I,k,k], s [N,I]; input_gain [], [I] or [N,I].  Returns [N,O,H+2p-k+1,W+2p-k+1] in x.dtype.
     `x_bound` (optional float): a guaranteed upper bound on |x|; enables the split-precision MFMA path (see `precision`).
     `prepared` (optional): this call's entry of `prepare_batch`, made from the same w, s, input_gain and x_bound.
-    `epilogue` (optional, inference only): (bias, clamp, scale) fused into the ToRGB kernel, see `torgb_epilogue_ok`."""
+    `epilogue` (optional, inference only): (bias, clamp, scale) fused into the ToRGB kernel, see `torgb_epilogue_ok`.
+    `align_rows` (optional, inference only): the result may be a [..., :W'] view of a buffer whose rows start on 128-byte lines
+    (faster stores for the 1046-wide layers; consumers must honour strides, as filtered_lrelu does)."""
     assert impl in ['ref', 'cuda']
     with misc.suppress_tracer_warnings():
         n = int(x.shape[0])
@@ -298,5 +312,6 @@ def modulated_conv2d(x, w, s, demodulate=True, padding=0, input_gain=None, impl=
     if impl == 'cuda' and x.device.type == 'cuda':
         if epilogue is not None and (torch.is_grad_enabled() or not torgb_epilogue_ok(w, padding, x.dtype)):
             raise RuntimeError('modulated_conv2d: the fused epilogue is for ToRGB-shaped inference calls only')
-        return _ModulatedConv2dHip.apply(x, w, s, input_gain, bool(demodulate), int(padding), x_bound, prepared, epilogue)
+        return _ModulatedConv2dHip.apply(x, w, s, input_gain, bool(demodulate), int(padding), x_bound, prepared, epilogue,
+                                         bool(align_rows) and not torch.is_grad_enabled())
     return _composite(x, w, s, demodulate, padding, input_gain)

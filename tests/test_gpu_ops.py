@@ -617,3 +617,24 @@ def test_filtered_lrelu_non_finite_input_stays_loud(shape, up, taps, pad, radial
         assert np.array_equal(y[0, plane][:, ~nan_cols], y_clean[0, plane][:, ~nan_cols])
     ok = np.isfinite(y) & np.isfinite(ref)
     assert float(np.abs(y[ok] - ref[ok]).max()) <= 2e-5 * max(1.0, float(np.abs(ref[ok]).max()))
+
+
+@pytest.mark.parametrize('n,ci,co,h', [(2, 51, 32, 150), (1, 81, 51, 278), (1, 64, 70, 131)])
+def test_modulated_conv2d_aligned_row_pitch(n, ci, co, h):
+    """`align_rows`: the 3x3 split-precision kernel writes into a buffer whose rows start on 128-byte lines and returns the
+    [..., :W'] view; values are bit-identical to the dense call, and filtered_lrelu consumes the strided view as it stands."""
+    from oracle import oracle as O
+    from torch_utils.ops import filtered_lrelu as fl, modulated_conv
+    x = T(rand(41, n, ci, h, h)); w = T(rand(42, co, ci, 3, 3)); s = T(rand(43, n, ci) + 1.5)
+    with torch.no_grad():
+        dense = modulated_conv.modulated_conv2d(x, w, s, demodulate=True, padding=2, x_bound=8.0)
+        view = modulated_conv.modulated_conv2d(x, w, s, demodulate=True, padding=2, x_bound=8.0, align_rows=True)
+        assert tuple(view.shape) == tuple(dense.shape) and torch.equal(view, dense)
+        assert view.stride(3) == 1 and view.stride(2) % 32 == 0 and view.stride(2) >= view.shape[3] and not view.is_contiguous()
+        fu = T(O.design_lowpass_filter(12, 4.0, 8.0, 64.0)); fd = T(O.design_lowpass_filter(12, 5.0, 9.0, 64.0))
+        b = T(rand(44, co))
+        kw = dict(up=2, down=2, padding=[9, 8, 9, 8], gain=float(np.sqrt(2)), slope=0.2, clamp=256)
+        assert torch.equal(fl.filtered_lrelu(view, fu, fd, b, **kw), fl.filtered_lrelu(dense, fu, fd, b, **kw))
+    # with gradients recorded the request is ignored (the autograd graph keeps dense tensors)
+    xg = x.clone().requires_grad_(True)
+    assert modulated_conv.modulated_conv2d(xg, w, s, demodulate=True, padding=2, x_bound=8.0, align_rows=True).is_contiguous()
