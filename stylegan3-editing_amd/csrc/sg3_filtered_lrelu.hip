@@ -282,7 +282,7 @@ struct Stream {
     template <int S>
     static __device__ __forceinline__ void step(State& st, const StreamParams& p, const T* __restrict__ plane, T* __restrict__ oplane,
                                                 unsigned char* __restrict__ splane, lds_f* sIn, lds_f* sOut, int i, int delta, int lane,
-                                                int oy0, int oy1, int ox0, int oxN, bool pairStore, unsigned long long& poison) {
+                                                int oy0, int oy1, int ox0, int oxN, bool pairStore, float& liveGain) {
         constexpr bool RDOWN = RADIAL == 1 || RADIAL == 2 || RADIAL >= 5;   // full 12x12 DOWN filter (config R forward)
         constexpr bool FOLD = RADIAL >= 5;                         // ... whose rows read the same in both directions
         constexpr bool UP2D = RADIAL == 3 || RADIAL == 4;          // full 12x12 UP filter (adjoint of those layers)
@@ -295,8 +295,8 @@ struct Stream {
         // into -clamp, while the reference's `if (fabsf(v) > clamp) v = copysign(clamp, v)` (filtered_lrelu.cu:412-419) lets it
         // through; a NaN-preserving clamp costs an instruction per upsampled sample (8 %), and a wave-uniform branch to one cost 5 %
         // (measured: it fences the scheduler).  Instead every sample a lane stages is classified (one v_cmp_class per load: NaN or
-        // infinity, which meets taps of both signs in the filter), the lane masks are OR-ed on the scalar unit, and from the row a
-        // wave has met one on, its output gain is NaN: every output it still writes in this strip is NaN.  That is a superset of the
+        // infinity, which meets taps of both signs in the filter) and from the row a wave has met one on, its output gain -- one
+        // scalar register, overwritten in place -- is NaN: every output it still writes in this strip is NaN.  That is a superset of the
         // reference's NaN footprint (a failure stays loud and stays where it happened), at no cost inside the nonlinearity.  The
         // last load of a row holds the strip's 6 halo samples, which the neighbouring strip classifies as its own: left out here.
         if (SIGNS == 0 && SG3_NAN_GUARD) {
@@ -304,7 +304,8 @@ struct Stream {
             for (int q = 0; q < Cfg::NL - 1; q++) {
                 unsigned long long m;            // asm: the file is built with -fno-honor-nans, which folds the NaN classes away
                 asm("v_cmp_class_f32 %0, %1, %2" : "=s"(m) : "v"(st.pre[PS][q]), "s"(0x207));
-                poison |= m;
+                // the output gain itself carries the state (one scalar register that is live anyway: the radial kernels have none to spare)
+                liveGain = m != 0ull ? __builtin_bit_cast(float, 0x7fc00000u) : liveGain;
             }
         }
         unsigned sgNow[U];               // this row's sign bytes: the prefetch below reuses their slot
@@ -340,8 +341,7 @@ struct Stream {
         // ---- U new upsampled rows ----
         const float slope = p.slope, clampv = p.clamp / p.gain, gain = p.gain;
         // sign-write mode applies the gain before the nonlinearity; the 2-D up filter's taps carry no up^2 factor
-        const float gainOut = (SIGNS == 1) ? 1.f : (UP2D ? p.gain * (float)(U * U) :
-                              ((SIGNS == 0 && SG3_NAN_GUARD && poison != 0ull) ? __builtin_bit_cast(float, 0x7fc00000u) : p.gain));
+        const float gainOut = (SIGNS == 1) ? 1.f : (UP2D ? p.gain * (float)(U * U) : ((SIGNS == 0 && SG3_NAN_GUARD) ? liveGain : p.gain));
 #pragma unroll
         for (int j = 0; j < U; j++) {
             const int kv = U - 1 - j;                          // vertical up phase of this row
@@ -652,7 +652,7 @@ struct Stream {
         }
 
         st.osum = 0.f;
-        unsigned long long poison = 0ull;         // lanes that have staged a non-finite sample so far (wave-uniform, scalar registers)
+        float liveGain = p.gain;                  // the output gain; NaN from the row on in which this wave staged a non-finite sample
         if (SIGNS) {
             const int c0 = uxs + p.sx;                           // sign-tensor column of lane 0's first upsampled column
             st.sq = to_sgpr_i(((c0 % 4) + 4) % 4);
@@ -680,12 +680,12 @@ struct Stream {
 
         int i = iFirst;
         for (int blk = 0; blk < nBlocks; blk++, i += 6) {
-            step<0>(st, p, plane, oplane, splane, sIn, sOut, i + 0, delta, lane, oy0, oy1, ox0, oxN, pairStore, poison);
-            step<1>(st, p, plane, oplane, splane, sIn, sOut, i + 1, delta, lane, oy0, oy1, ox0, oxN, pairStore, poison);
-            step<2>(st, p, plane, oplane, splane, sIn, sOut, i + 2, delta, lane, oy0, oy1, ox0, oxN, pairStore, poison);
-            step<3>(st, p, plane, oplane, splane, sIn, sOut, i + 3, delta, lane, oy0, oy1, ox0, oxN, pairStore, poison);
-            step<4>(st, p, plane, oplane, splane, sIn, sOut, i + 4, delta, lane, oy0, oy1, ox0, oxN, pairStore, poison);
-            step<5>(st, p, plane, oplane, splane, sIn, sOut, i + 5, delta, lane, oy0, oy1, ox0, oxN, pairStore, poison);
+            step<0>(st, p, plane, oplane, splane, sIn, sOut, i + 0, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain);
+            step<1>(st, p, plane, oplane, splane, sIn, sOut, i + 1, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain);
+            step<2>(st, p, plane, oplane, splane, sIn, sOut, i + 2, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain);
+            step<3>(st, p, plane, oplane, splane, sIn, sOut, i + 3, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain);
+            step<4>(st, p, plane, oplane, splane, sIn, sOut, i + 4, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain);
+            step<5>(st, p, plane, oplane, splane, sIn, sOut, i + 5, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain);
             if ((6 * U / D) % 6 != 0) {
                 // a trip completes 6U/D output rows; when that is 3 (U = 2, D = 4) the ring of output rows has turned by
                 // half: swap the halves so that the compile-time slot numbering holds for the next trip
