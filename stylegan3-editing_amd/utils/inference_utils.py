@@ -8,7 +8,9 @@ import types
 
 import torch
 
+from models.setgan.encoder.e4e3 import e4e
 from models.setgan.encoder.psp3 import pSp
+from utils.model_utils import ENCODER_TYPES
 
 
 def load_encoder(checkpoint_path, test_opts=None, generator_path=None, device='cuda'):
@@ -18,7 +20,8 @@ def load_encoder(checkpoint_path, test_opts=None, generator_path=None, device='c
     if test_opts is not None:
         opts.update(test_opts if isinstance(test_opts, dict) else vars(test_opts))
     opts = types.SimpleNamespace(**opts)
-    net = pSp(opts)
+    # the checkpoint's encoder_type selects the wrapper (reference inference_utils.py:38-47)
+    net = pSp(opts) if opts.encoder_type in ENCODER_TYPES['pSp'] else e4e(opts)
     if generator_path is not None:
         from models.stylegan3.model import SG3Generator
         net.decoder = SG3Generator(checkpoint_path=generator_path, device='cpu').decoder

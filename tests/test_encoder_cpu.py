@@ -218,3 +218,43 @@ def test_inference_iterative_writes_latents_and_stats(tmp_path):
         _, direct = run_on_batch(images[4:5], net, opts, get_average_image(net))     # the ragged last batch (5 = 2 + 2 + 1)
     assert maxabs(loaded['00004.png'][2], direct[0][2]) <= 1e-6
     assert len(results['00000.png']) == 3 and tuple(results['00000.png'][0].shape) == (3, 64, 64)
+
+
+@pytest.mark.parametrize('family,encoder_type,n_styles', [('pSp', 'ResNetBackboneEncoder', 16), ('e4e', 'ProgressiveBackboneEncoder', 3)])
+def test_load_encoder_checkpoint_roundtrip(family, encoder_type, n_styles, tmp_path):
+    """The encoder checkpoint format of the reference (psp3.py:34-38, :108-114; inference_utils.py:28-56): `state_dict` with
+    `encoder.*` / `decoder.*` entries, `latent_avg`, `opts`; `load_encoder` picks pSp or e4e from `opts['encoder_type']`
+    (utils/model_utils.py), merges the test options over the stored ones and restores every tensor."""
+    from models.setgan.encoder.e4e3 import e4e
+    from models.setgan.encoder.psp3 import pSp
+    from models.stylegan3.model import SG3Generator
+    from utils.inference_utils import load_encoder
+    wrapper = {'pSp': pSp, 'e4e': e4e}[family]
+    stored = dict(encoder_type=encoder_type, input_nc=6, n_styles=n_styles, n_iters_per_batch=3, resize_outputs=False, stylegan_weights=None,
+                  checkpoint_path=None)
+    torch.manual_seed(3)
+    decoder = SG3Generator(checkpoint_path=None, device='cpu').decoder          # the reference's default: config R at 1024
+    src = wrapper(types.SimpleNamespace(**stored), decoder=decoder).eval()
+    with torch.no_grad():
+        for prm in src.encoder.parameters():
+            prm.add_(0.01 * torch.randn_like(prm))                              # away from the constructor's values
+        decoder.synthesis.input.transform = torch.eye(3).repeat(2, 1, 1)        # a batched call leaves this behind (psp3.py:37)
+    latent_avg = torch.randn(n_styles, 512)
+    state = {'encoder.' + k: v for k, v in src.encoder.state_dict().items()}
+    state.update({'decoder.' + k: v for k, v in decoder.state_dict().items()})
+    path = tmp_path / 'restyle.pt'
+    torch.save({'state_dict': state, 'latent_avg': latent_avg, 'opts': stored}, path)
+    net, opts = load_encoder(path, test_opts={'n_iters_per_batch': 2, 'test_batch_size': 4}, device='cpu')
+    assert type(net) is wrapper and type(net.encoder).__name__ == encoder_type and not net.training
+    assert opts.n_iters_per_batch == 2 and opts.test_batch_size == 4 and opts.encoder_type == encoder_type and opts.checkpoint_path == path
+    assert torch.equal(net.latent_avg, latent_avg) and net.n_styles == n_styles
+    for k, v in src.encoder.state_dict().items():
+        assert torch.equal(net.encoder.state_dict()[k], v), k
+    got = net.decoder.state_dict()
+    for k, v in decoder.state_dict().items():
+        if k != 'synthesis.input.transform':
+            assert torch.equal(got[k], v), k
+    assert tuple(got['synthesis.input.transform'].shape) == (3, 3)              # the shape-dependent buffer is not loaded
+    x = torch.from_numpy(_input()[:1])
+    with torch.no_grad():
+        assert maxabs(net.encoder(x).numpy(), src.encoder(x).numpy()) <= 1e-6
