@@ -1,5 +1,5 @@
-"""Input-transform helpers used by the inversion path (reference utils/common.py:9-45; tensor2im / mp4 writing need PIL /
-imageio and belong to the out-of-scope I/O layer).
+"""Input-transform helpers used by the inversion path and the two image helpers its callers use (reference utils/common.py:9-55).
+`tensor2im` needs PIL and `generate_mp4` imageio; both are imported when called (imageio is not installed in this image).
 
 A transform is the 3x3 matrix that `SynthesisInput` receives in `synthesis.input.transform`: the INVERSE of "rotate by
 `angle` degrees, then shift by `translate`" in the generator's [-1, 1] canvas units."""
@@ -26,3 +26,23 @@ def generate_random_transform(translate=0.3, rotate=25):
     angle = np.random.uniform(-rotate, rotate)
     shift = np.random.uniform(-translate, translate, size=2)
     return np.linalg.inv(make_transform(shift, angle))
+
+
+def tensor2im(var):
+    """CHW tensor in [-1, 1] -> PIL image, values truncated to uint8 (reference :39-45)."""
+    from PIL import Image
+    arr = var.cpu().detach().transpose(0, 2).transpose(0, 1).numpy()
+    arr = np.clip((arr + 1) / 2, 0, 1) * 255
+    return Image.fromarray(arr.astype('uint8'))
+
+
+def generate_mp4(out_name, images, kwargs):
+    """Write frames to `<out_name>.mp4` through imageio (reference :48-52)."""
+    try:
+        import imageio
+    except ImportError as err:
+        raise RuntimeError('generate_mp4 needs the imageio package (video writing is outside this package)') from err
+    writer = imageio.get_writer(str(out_name) + '.mp4', **kwargs)
+    for image in images:
+        writer.append_data(np.array(image))
+    writer.close()

@@ -162,3 +162,20 @@ def test_psp_forward_and_restyle_loop_oracle(cfg):
     assert maxabs(np.stack(imgs_on), g[f'restyle/{cfg}/on/images']) <= 1e-5 and maxabs(np.stack(imgs_off), g[f'restyle/{cfg}/off/images']) <= 1e-5
     assert maxabs(np.stack(lats_on), g[f'restyle/{cfg}/on/latents']) <= 1e-4 and maxabs(np.stack(lats_off), g[f'restyle/{cfg}/off/latents']) <= 1e-4
     assert maxabs(aligned_last, g[f'restyle/{cfg}/off/images'][-1]) <= 1e-5      # the aligned last step IS the transform-free result
+
+
+def test_tensor2im_matches_reference_frames():
+    """utils.common.tensor2im (reference :39-45) on the expanded frames of the video fixture: the same uint8 pixels the reference
+    wrote (the fixture's frames ARE np.array(tensor2im(...)) of the reference)."""
+    from utils.common import tensor2im
+    from utils.fov_expansion import Expander
+    from oracle import oracle as O
+    g = golden('callers')
+    G = build_product_generator('Ttiny')
+    lat, tr = _video_case()
+    sm = O.postprocess_latents(lat)
+    sm_tr = O.smooth_ws(np.stack(tr))
+    im = Expander(G, force_fp32=True).generate_expanded_image(ws=torch.from_numpy(sm[:1].astype(np.float32)), landmark_t=sm_tr[0], pixels_left=4, pixels_right=2, pixels_top=0, pixels_bottom=3)
+    frame = np.array(tensor2im(im[0]))
+    assert frame.dtype == np.uint8 and frame.shape == g['video/frames'][0].shape
+    assert np.abs(frame.astype(np.int32) - g['video/frames'][0].astype(np.int32)).max() <= 1
