@@ -123,3 +123,24 @@ def test_psp_forward_and_restyle_loop_match_reference_fixture(cfg):
     n0 = _sg3abi.launch_count
     check_loop_against_golden(net, opts, cfg, DEV, tol_img=1e-4, tol_lat=1e-5)
     assert _sg3abi.launch_count - n0 > 300, 'the decoder did not run on the HIP kernels'
+
+
+def test_run_on_batch_with_resnet34_encoder_matches_oracle():
+    """The ReStyle loop with the ResNet34 backbone (`encoder_type='ResNetBackboneEncoder'`, reference restyle_psp_encoders.py:53-97)
+    on the HIP path against the oracle loop driven by the oracle's ResNet34 restatement: 2 steps, landmark transforms on."""
+    from oracle import oracle as O
+    from utils.inference_utils import get_average_image, run_on_batch
+    net, opts, enc_sd, gen_sd, sched = build_restyle_pair('Rmini', device=DEV, encoder_type='ResNetBackboneEncoder', n_iters=2)
+    assert type(net.encoder).__name__ == 'ResNetBackboneEncoder'
+    lat_avg = gen_sd['mapping.w_avg']
+    x, lt = _frames(2, seed=8), _landmarks(2)
+    enc = lambda x6: O.resnet_backbone_encoder(enc_sd, x6, n_styles=16)  # noqa: E731
+    avg_o = O.get_average_image(None, gen_sd, sched, lat_avg)
+    imgs_o, lats_o, _ = O.run_on_batch(None, gen_sd, sched, x, lat_avg, avg_o, 2, landmarks_transform=lt, encoder=enc)
+    with torch.no_grad():
+        avg = get_average_image(net)
+        imgs, lats = run_on_batch(torch.from_numpy(x).to(DEV), net, opts, avg, landmarks_transform=torch.from_numpy(lt).to(DEV))
+    for it in range(2):
+        got_l = np.stack([lats[i][it] for i in range(2)])
+        assert maxabs(got_l, lats_o[it]) <= 2e-4 * max(1.0, float(np.abs(lats_o[it]).max())), it
+        assert maxabs(torch.stack([imgs[i][it] for i in range(2)]).cpu().numpy(), imgs_o[it]) <= 1e-4, it
