@@ -115,6 +115,12 @@ SG3_API int sg3_filtered_lrelu(const sg3_filtered_lrelu_params* p, void* stream)
 /* number of partial sums per (n,c) plane that sg3_filtered_lrelu writes to ySumPartial for this output shape */
 SG3_API int sg3_filtered_lrelu_sum_slots(int N, int C, int yH, int yW, int down);
 
+/* Host-only query: how many (n,c) planes one wave of the streaming kernel works on for this call -- 2 for the plain forward on
+ * narrow dense planes (output at most 54 columns wide, even C: the 36^2 .. 52^2 layers); 3 = mixed: rows cut into 120-column
+ * strips with one plane per wave plus a remainder strip of at most 54 columns with two (the 148^2 .. 532^2 layers); 1 otherwise;
+ * 0 when the call does not take the streaming kernel.  For tests and profiling; no reference counterpart. */
+SG3_API int sg3_filtered_lrelu_planes_per_wave(const sg3_filtered_lrelu_params* p);
+
 /* 1 when sg3_filtered_lrelu has a fused kernel for this tuple (host-only
  * query; mirrors the reference's choose_filtered_lrelu_kernel test call,
  * torch_utils/ops/filtered_lrelu.cpp:46-56). */

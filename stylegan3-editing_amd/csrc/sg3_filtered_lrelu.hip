@@ -40,6 +40,7 @@
 // Algorithmic traffic: C*(xH*xW + yH*yW)*sizeof(T) bytes per image -- the roofline figure bench.py uses.
 #include "sg3_common.h"
 #include <cmath>
+#include <cstdlib>
 
 // rows of input the streaming kernel keeps in flight per wave (each costs NL registers per lane): three rows are ~3 x 1.5 us
 // of work, several HBM latencies
@@ -63,11 +64,15 @@ typedef __attribute__((address_space(3))) v4f lds_v4f;
 struct StreamParams {
     const void* x; void* y; const void* b; const float* fu; const float* fd;
     int C, xH, xW, yH, yW;
+    int planes;                    // N * C
     long long xsN, xsC, xsH;      // element strides (innermost stride is 1)
     long long ysN, ysC, ysH;
     long long bStride;
     int px0, py0;
-    int TW;                        // output columns per strip (<= 120)
+    int TW;                        // output columns per strip (<= 122)
+    int ox0Base;                   // first output column of strip 0 (one-plane blocks) / of the packed strip (two-plane blocks)
+    int wideBlocks;                // G = 2 kernels: the first wideBlocks (logical) blocks work on ONE plane each, strips of TW columns
+                                   // from column 0; the others on two planes, columns ox0Base .. yW - 1
     int CH;                        // output rows per chunk
     int nStrips, nChunks;
     int totalBlocks;
@@ -198,6 +203,14 @@ template <int U, int D> struct StreamCfg {
     static constexpr int SIN = NL * 64;                 // LDS floats for the input row
     static constexpr int SOUT = 4 + 256 + 32;           // LDS floats for the output row (+ read-ahead of the last lanes)
     static constexpr int MAXTW = (256 - FD) / D;        // output columns a wave's 256 upsampled columns can complete
+    // packed mode (two narrow planes per wave, 32 lanes each): input-row / output-row LDS segment of one plane, and the widest
+    // output 32 lanes complete
+    static constexpr int PSEG = GROUPS * 32 + 8;        // 72 (up 2) | 40 (up 4) input samples; 2 PSEG <= SIN
+    static constexpr int POSEG = 4 * 32 + 16;           // 144 floats; 2 POSEG <= SOUT
+    // output column 2l + 1 reads the exchanged row up to slot 4 + 4l + 13, and the 32 lanes write slots 4 - delta .. 131 - delta
+    // (delta <= 3): l <= 26
+    static constexpr int PACKTW = 2 * 27;               // 54 output columns (down 2)
+    static_assert(2 * PSEG <= SIN && 2 * POSEG <= SOUT, "packed LDS rows fit the unpacked ones");
 };
 
 // element <-> fp32 through raw buffer instructions: the hardware range check (offset >= num_records reads 0 /
@@ -244,11 +257,17 @@ struct WaveState {
     float osum;                   // running sum of the outputs this lane stored (only kept when p.ysum is given)
     int soff;                     // sign modes: byte offset, inside a sign row, of the byte holding this lane's first column
     int sq;                       // sign modes: position (0..3) of that column inside its byte (wave-uniform)
+    int inBase, outBase;          // packed mode: this lane's window start in the input LDS row / its 4 samples' place in the output LDS row
+    int ooff[2];                  // packed mode: byte offsets of this lane's two output columns from the first plane's row (out of range: none)
 };
 
 // SIGNS: 0 = plain forward; 1 = forward that also writes the sign tensor (training); 2 = adjoint pass: the stored signs
 // replace the nonlinearity (gradient of lrelu + clamp).
-template <typename T, int U, int D, int VPH, int RADIAL, int SIGNS>
+// G: planes per wave.  2 = packed mode for narrow planes (yW <= PACKTW, one strip): lanes 0-31 work on plane 2k, lanes 32-63 on plane
+// 2k + 1, with their own segments of the two LDS rows -- the 36^2 .. 52^2 layers use 21 .. 29 lanes of a wave otherwise, and the
+// kernel's time there is its instruction count.  Plain forward only; tensors dense over (n, c) so that plane 2k + 1 sits one
+// channel stride after plane 2k (also across the end of an image).
+template <typename T, int U, int D, int VPH, int RADIAL, int SIGNS, int G = 1>
 struct Stream {
     typedef StreamCfg<U, D> Cfg;
     typedef WaveState<T, U, D> State;
@@ -258,7 +277,9 @@ struct Stream {
                                                     const unsigned char* __restrict__ splane, int i) {
         const bool rowOk = (unsigned)i < (unsigned)p.xH;
         const T* row = plane + (long long)i * p.xsH;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)row, (short)0, rowOk ? p.xW * (int)sizeof(T) : 0, 0x00020000);
+        // packed: the descriptor spans the same row of both planes (the lanes' offsets carry the plane and the column range check)
+        const int rowBytes = (G > 1 ? (int)p.xsC + p.xW : p.xW) * (int)sizeof(T);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)row, (short)0, rowOk ? rowBytes : 0, 0x00020000);
         const float rowFlag = rowOk ? 1.f : 0.f;
 #pragma unroll
         for (int q = 0; q < Cfg::NL; q++)
@@ -282,7 +303,7 @@ struct Stream {
     template <int S>
     static __device__ __forceinline__ void step(State& st, const StreamParams& p, const T* __restrict__ plane, T* __restrict__ oplane,
                                                 unsigned char* __restrict__ splane, lds_f* sIn, lds_f* sOut, int i, int delta, int lane,
-                                                int oy0, int oy1, int ox0, int oxN, bool pairStore, float& liveGain) {
+                                                int oy0, int oy1, int ox0, int oxN, bool pairStore, float& liveGain, float& liveGain1, bool wide) {
         constexpr bool RDOWN = RADIAL == 1 || RADIAL == 2 || RADIAL >= 5;   // full 12x12 DOWN filter (config R forward)
         constexpr bool FOLD = RADIAL >= 5;                         // ... whose rows read the same in both directions
         constexpr bool UP2D = RADIAL == 3 || RADIAL == 4;          // full 12x12 UP filter (adjoint of those layers)
@@ -299,7 +320,21 @@ struct Stream {
         // scalar register, overwritten in place -- is NaN: every output it still writes in this strip is NaN.  That is a superset of the
         // reference's NaN footprint (a failure stays loud and stays where it happened), at no cost inside the nonlinearity.  The
         // last load of a row holds the strip's 6 halo samples, which the neighbouring strip classifies as its own: left out here.
-        if (SIGNS == 0 && SG3_NAN_GUARD) {
+        if (SIGNS == 0 && SG3_NAN_GUARD && G > 1) {
+            // packed: every load is the wave's own (no neighbouring strip); staging lane e = lane + 64 q belongs to the first plane
+            // while e < PSEG -- each plane has its own gain register
+#pragma unroll
+            for (int q = 0; q < Cfg::NL; q++) {
+                unsigned long long m;
+                asm("v_cmp_class_f32 %0, %1, %2" : "=s"(m) : "v"(st.pre[PS][q]), "s"(0x207));
+                const int n0 = Cfg::PSEG - 64 * q;                                   // lanes of this load that stage the first plane
+                const unsigned long long first = n0 >= 64 ? ~0ull : (n0 <= 0 ? 0ull : ((1ull << (n0 & 63)) - 1ull));
+                // one-plane blocks: both registers follow the one plane, the last load (halo) left out as in the one-plane kernel
+                const unsigned long long mw = q < Cfg::NL - 1 ? m : 0ull;
+                liveGain = (wide ? mw : (m & first)) != 0ull ? __builtin_bit_cast(float, 0x7fc00000u) : liveGain;
+                liveGain1 = (wide ? mw : (m & ~first)) != 0ull ? __builtin_bit_cast(float, 0x7fc00000u) : liveGain1;
+            }
+        } else if (SIGNS == 0 && SG3_NAN_GUARD) {
 #pragma unroll
             for (int q = 0; q < Cfg::NL - 1; q++) {
                 unsigned long long m;            // asm: the file is built with -fno-honor-nans, which folds the NaN classes away
@@ -316,7 +351,7 @@ struct Stream {
         if (U == 2) {
             float xs[8];
             // volatile: keeps four ds_read_b64 (2 LDS cycles each); merged into ds_read2_b64 they run at a quarter of that
-            const volatile lds_v2f* src = reinterpret_cast<const volatile lds_v2f*>(sIn + 2 * lane);
+            const volatile lds_v2f* src = reinterpret_cast<const volatile lds_v2f*>(sIn + (G > 1 ? st.inBase : 2 * lane));
 #pragma unroll
             for (int q = 0; q < 4; q++) { v2f t = src[q]; xs[2 * q] = t.x; xs[2 * q + 1] = t.y; if (UP2D) st.xw[S][q] = t; }
 #pragma unroll
@@ -329,7 +364,7 @@ struct Stream {
         } else {  // U == 4: the lane's four columns are the four phases of one input window
             float xs[6];
 #pragma unroll
-            for (int t = 0; t < 6; t++) xs[t] = sIn[lane + t];
+            for (int t = 0; t < 6; t++) xs[t] = sIn[(G > 1 ? st.inBase : lane) + t];
             v2f a0 = splat(xs[0]) * st.tuP[1], a1 = splat(xs[0]) * st.tuP[0];
 #pragma unroll
             for (int t = 1; t < 6; t++) {
@@ -341,7 +376,7 @@ struct Stream {
         // ---- U new upsampled rows ----
         const float slope = p.slope, clampv = p.clamp / p.gain, gain = p.gain;
         // sign-write mode applies the gain before the nonlinearity; the 2-D up filter's taps carry no up^2 factor
-        const float gainOut = (SIGNS == 1) ? 1.f : (UP2D ? p.gain * (float)(U * U) : ((SIGNS == 0 && SG3_NAN_GUARD) ? liveGain : p.gain));
+        const float gainOut = (SIGNS == 1) ? 1.f : (UP2D ? p.gain * (float)(U * U) : ((SIGNS == 0 && SG3_NAN_GUARD) ? ((G > 1 && lane >= 32) ? liveGain1 : liveGain) : p.gain));
 #pragma unroll
         for (int j = 0; j < U; j++) {
             const int kv = U - 1 - j;                          // vertical up phase of this row
@@ -444,10 +479,10 @@ struct Stream {
                 // the 16 samples under its two output columns) and scattered into the six output rows it belongs to, one
                 // even/odd polyphase pass per output row with that row's 12 taps.  The 144 taps do not fit the scalar
                 // registers: they stream through the scalar cache (s_load) as SGPR pairs, off the LDS and VALU paths.
-                lds_f* dstr = sOut + (4 - delta) + 4 * lane;
+                lds_f* dstr = sOut + (4 - delta) + (G > 1 ? st.outBase : 4 * lane);
                 dstr[0] = r0.x; dstr[1] = r0.y; dstr[2] = r1.x; dstr[3] = r1.y;
                 wave_lds_sync();
-                const lds_v4f* srcr = reinterpret_cast<const lds_v4f*>(sOut + 4 + 4 * lane);
+                const lds_v4f* srcr = reinterpret_cast<const lds_v4f*>(sOut + 4 + (G > 1 ? st.outBase : 4 * lane));
                 v2f pr[8];
 #pragma unroll
                 for (int q = 0; q < 4; q++) { const v4f t = srcr[q]; pr[2 * q] = (v2f){t.x, t.y}; pr[2 * q + 1] = (v2f){t.z, t.w}; }
@@ -507,12 +542,12 @@ struct Stream {
                         const float f0 = (y0.x + y0.y) * gainOut, f1 = (y1.x + y1.y) * gainOut;
                         if (SIGNS == 2) st.osum += (2 * lane < oxN ? f0 : 0.f) + (2 * lane + 1 < oxN ? f1 : 0.f);
                         T* orow = oplane + (long long)oy * p.ysH + ox0;
-                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)orow, (short)0, oxN * (int)sizeof(T), 0x00020000);
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)orow, (short)0, (G > 1 ? (int)p.ysC + oxN : oxN) * (int)sizeof(T), 0x00020000);
                         if (pairStore) {
-                            bufio<T>::st2(rs, 2 * lane * (int)sizeof(T), f0, f1);
+                            bufio<T>::st2(rs, G > 1 ? st.ooff[0] : 2 * lane * (int)sizeof(T), f0, f1);
                         } else {
-                            bufio<T>::st1(rs, 2 * lane * (int)sizeof(T), f0);
-                            bufio<T>::st1(rs, (2 * lane + 1) * (int)sizeof(T), f1);
+                            bufio<T>::st1(rs, G > 1 ? st.ooff[0] : 2 * lane * (int)sizeof(T), f0);
+                            bufio<T>::st1(rs, G > 1 ? st.ooff[1] : (2 * lane + 1) * (int)sizeof(T), f1);
                         }
                     }
                 }
@@ -540,12 +575,12 @@ struct Stream {
                 const int oy = (uy - (Cfg::FD - 1)) / D;       // exact
                 if (oy >= oy0 && oy < oy1) {                   // wave-uniform
                     const v2f o0 = st.acc[headNow][0], o1 = st.acc[headNow][1];
-                    lds_f* dst = sOut + (4 - delta) + 4 * lane;
+                    lds_f* dst = sOut + (4 - delta) + (G > 1 ? st.outBase : 4 * lane);
                     dst[0] = o0.x; dst[1] = o0.y; dst[2] = o1.x; dst[3] = o1.y;
                     wave_lds_sync();
                     T* orow = oplane + (long long)oy * p.ysH + ox0;
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)orow, (short)0, oxN * (int)sizeof(T), 0x00020000);
-                    const lds_v4f* src = reinterpret_cast<const lds_v4f*>(sOut + 4 + 4 * lane);
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)orow, (short)0, (G > 1 ? (int)p.ysC + oxN : oxN) * (int)sizeof(T), 0x00020000);
+                    const lds_v4f* src = reinterpret_cast<const lds_v4f*>(sOut + 4 + (G > 1 ? st.outBase : 4 * lane));
                     if (D == 2) {
                         // lane l -> output columns 2l, 2l+1: upsampled samples 4l .. 4l+13 (+4 pad), four aligned b128 reads
                         v2f pr[8];
@@ -557,10 +592,10 @@ struct Stream {
                         const float f0 = (y0.x + y0.y) * gainOut, f1 = (y1.x + y1.y) * gainOut;
                         if (SIGNS == 2) st.osum += (2 * lane < oxN ? f0 : 0.f) + (2 * lane + 1 < oxN ? f1 : 0.f);
                         if (pairStore) {
-                            bufio<T>::st2(rs, 2 * lane * (int)sizeof(T), f0, f1);
+                            bufio<T>::st2(rs, G > 1 ? st.ooff[0] : 2 * lane * (int)sizeof(T), f0, f1);
                         } else {
-                            bufio<T>::st1(rs, 2 * lane * (int)sizeof(T), f0);
-                            bufio<T>::st1(rs, (2 * lane + 1) * (int)sizeof(T), f1);
+                            bufio<T>::st1(rs, G > 1 ? st.ooff[0] : 2 * lane * (int)sizeof(T), f0);
+                            bufio<T>::st1(rs, G > 1 ? st.ooff[1] : (2 * lane + 1) * (int)sizeof(T), f1);
                         }
                     } else {
                         // D == 4: lane l -> output column l: upsampled samples 4l .. 4l+23, six aligned b128 reads
@@ -587,6 +622,7 @@ struct Stream {
         static_assert(RADIAL >= 0 && RADIAL <= 6, "RADIAL: 0 separable, 1/2 12x12 down, 3/4 12x12 up, 5/6 12x12 down with mirror-symmetric rows");
         static_assert(!RDOWN || (D == 2 && SIGNS != 2), "radial down filter: forward passes (plain or sign-writing), down 2");
         static_assert(!UP2D || (U == 2 && SIGNS == 2), "2-D up filter: the adjoint pass, up 2");
+        static_assert(G == 1 || (G == 2 && SIGNS == 0 && D == 2), "packed mode: plain forward, down 2, two planes");
         __shared__ __attribute__((aligned(16))) float lds[Cfg::SIN + Cfg::SOUT];
         lds_f* sIn = (lds_f*)lds;
         lds_f* sOut = (lds_f*)lds + Cfg::SIN;                               // row exchanged for the horizontal down pass
@@ -601,13 +637,18 @@ struct Stream {
             const int nb = p.totalBlocks, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
             bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
         }
-        const int strip = bid % p.nStrips;
-        const int chunk = (bid / p.nStrips) % p.nChunks;
-        const int plane_id = bid / (p.nStrips * p.nChunks);
+        // a G = 2 kernel runs both forms: its first wideBlocks blocks take the full-width strips of the rows, one plane each, the
+        // others the remainder strip (or the whole row, when it is narrow) of two planes each.  Wave-uniform.
+        const bool wide = G > 1 && bid < p.wideBlocks;
+        const bool two = G > 1 && !wide;
+        const int pbid = two ? bid - p.wideBlocks : bid;
+        const int strip = two ? 0 : pbid % p.nStrips;
+        const int chunk = two ? pbid % p.nChunks : (pbid / p.nStrips) % p.nChunks;
+        const int plane_id = two ? (pbid / p.nChunks) * 2 : pbid / (p.nStrips * p.nChunks);      // two: the first of this wave's planes
         const int n = plane_id / p.C, c = plane_id - n * p.C;
 
-        const int ox0 = strip * p.TW;
-        const int oxN = min(p.TW, p.yW - ox0);
+        const int ox0 = (G > 1 && wide) ? strip * p.TW : p.ox0Base + strip * p.TW;
+        const int oxN = two ? p.yW - ox0 : min(p.TW, p.yW - ox0);
         const int oy0 = chunk * p.CH;
         const int oy1 = min(oy0 + p.CH, p.yH);
 
@@ -617,7 +658,11 @@ struct Stream {
         unsigned char* splane = SIGNS ? p.s + (long long)plane_id * p.sH * p.sWb : nullptr;
         // a pair store must not straddle the end of the row (and fp16 pairs must be dword aligned)
         const bool pairStore = ((oxN & 1) == 0) &&
-            (sizeof(T) == 4 || (((((unsigned long long)oplane >> 1) + (unsigned long long)ox0) & 1) == 0 && (p.ysH & 1) == 0));
+            (sizeof(T) == 4 || (((((unsigned long long)oplane >> 1) + (unsigned long long)ox0) & 1) == 0 && (p.ysH & 1) == 0 && (G == 1 || (p.ysC & 1) == 0)));
+        // packed: the second plane is the next one of the dense (n, c) order -- channel 0 of the next image after the last channel;
+        // an odd number of planes leaves the last wave without one
+        const bool second = two && plane_id + 1 < p.planes;
+        const float bias1 = (second && p.b) ? io<T>::ld((const T*)p.b + (long long)(c + 1 == p.C ? 0 : c + 1) * p.bStride) : 0.f;
 
         State st;
         // taps -> scalar register pairs; effective correlation taps g[k] = f[flip ? k : taps-1-k]
@@ -646,13 +691,32 @@ struct Stream {
         const int ibase = floor_div(uxs - p.px0 - 1, U) + 1;
 #pragma unroll
         for (int q = 0; q < Cfg::NL; q++) {
+            if (G > 1) {
+                // staging slot e of the LDS row: plane e / PSEG, sample e % PSEG of that plane's window
+                // (one-plane blocks: the whole row is that plane's)
+                const int e = lane + 64 * q, g = (two && e >= Cfg::PSEG) ? 1 : 0;
+                const int ix = ibase + e - g * Cfg::PSEG;
+                const bool ok = (wide || e < 2 * Cfg::PSEG) && (unsigned)ix < (unsigned)p.xW && (g == 0 || second);
+                st.coff[q] = ok ? (g * (int)p.xsC + ix) * (int)sizeof(T) : (int)0x80000000;
+                st.bcol[q] = ok ? (g ? bias1 : bias) : 0.f;
+                continue;
+            }
             const int ix = ibase + lane + 64 * q;
             st.coff[q] = ix * (int)sizeof(T);                  // negative / beyond the row -> out of range -> reads 0
             st.bcol[q] = ((unsigned)ix < (unsigned)p.xW) ? bias : 0.f;
         }
+        if (G > 1) {
+            const int g = two ? lane >> 5 : 0, ll = two ? lane & 31 : lane;
+            st.inBase = g * Cfg::PSEG + Cfg::GROUPS * ll;
+            st.outBase = g * Cfg::POSEG + 4 * ll;
+            const bool mine = g == 0 || second;
+            st.ooff[0] = (mine && 2 * ll < oxN) ? (g * (int)p.ysC + 2 * ll) * (int)sizeof(T) : (int)0x80000000;
+            st.ooff[1] = (mine && 2 * ll + 1 < oxN) ? (g * (int)p.ysC + 2 * ll + 1) * (int)sizeof(T) : (int)0x80000000;
+        }
 
         st.osum = 0.f;
         float liveGain = p.gain;                  // the output gain; NaN from the row on in which this wave staged a non-finite sample
+        float liveGain1 = p.gain;                 // packed mode: the second plane's
         if (SIGNS) {
             const int c0 = uxs + p.sx;                           // sign-tensor column of lane 0's first upsampled column
             st.sq = to_sgpr_i(((c0 % 4) + 4) % 4);
@@ -680,12 +744,12 @@ struct Stream {
 
         int i = iFirst;
         for (int blk = 0; blk < nBlocks; blk++, i += 6) {
-            step<0>(st, p, plane, oplane, splane, sIn, sOut, i + 0, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain);
-            step<1>(st, p, plane, oplane, splane, sIn, sOut, i + 1, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain);
-            step<2>(st, p, plane, oplane, splane, sIn, sOut, i + 2, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain);
-            step<3>(st, p, plane, oplane, splane, sIn, sOut, i + 3, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain);
-            step<4>(st, p, plane, oplane, splane, sIn, sOut, i + 4, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain);
-            step<5>(st, p, plane, oplane, splane, sIn, sOut, i + 5, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain);
+            step<0>(st, p, plane, oplane, splane, sIn, sOut, i + 0, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain, liveGain1, wide);
+            step<1>(st, p, plane, oplane, splane, sIn, sOut, i + 1, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain, liveGain1, wide);
+            step<2>(st, p, plane, oplane, splane, sIn, sOut, i + 2, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain, liveGain1, wide);
+            step<3>(st, p, plane, oplane, splane, sIn, sOut, i + 3, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain, liveGain1, wide);
+            step<4>(st, p, plane, oplane, splane, sIn, sOut, i + 4, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain, liveGain1, wide);
+            step<5>(st, p, plane, oplane, splane, sIn, sOut, i + 5, delta, lane, oy0, oy1, ox0, oxN, pairStore, liveGain, liveGain1, wide);
             if ((6 * U / D) % 6 != 0) {
                 // a trip completes 6U/D output rows; when that is 3 (U = 2, D = 4) the ring of output rows has turned by
                 // half: swap the halves so that the compile-time slot numbering holds for the next trip
@@ -710,10 +774,10 @@ struct Stream {
     }
 };
 
-template <typename T, int U, int D, int VPH, int RADIAL, int SIGNS>
+template <typename T, int U, int D, int VPH, int RADIAL, int SIGNS, int G = 1>
 __global__ void __launch_bounds__(64)
 flrelu_stream_kernel(StreamParams p) {
-    Stream<T, U, D, VPH, RADIAL, SIGNS>::run(p);
+    Stream<T, U, D, VPH, RADIAL, SIGNS, G>::run(p);
 }
 
 // ---------------------------------------------------------------------------
@@ -794,11 +858,31 @@ static void stream_grid(int N, int C, int yH, int yW, int down, int& nStrips, in
     nChunks = ceil_div(yH, CH);
 }
 
+// Two planes per wave (packed mode of the streaming kernel) for the plain forward on strips at most `width` columns wide: dense
+// (n, c) planes (the second plane of a wave sits one channel stride after the first), offsets inside a 2 GB descriptor.
+// SG3_FLRELU_NOPACK=1 in the environment keeps one plane per wave (A/B timing; read once).
+static bool stream_packs_planes(const sg3_filtered_lrelu_params& q, int width) {
+    static const bool allowed = [] { const char* e = getenv("SG3_FLRELU_NOPACK"); return !(e && e[0] == '1'); }();
+    const long long esz = q.dtype == SG3_F32 ? 4 : 2;
+    const long long xsC = q.xStride[1], ysC = q.yStride[1];
+    return allowed && !q.readSigns && !q.writeSigns && q.down == 2 && width <= StreamCfg<2, 2>::PACKTW &&
+           q.xStride[0] == (long long)q.C * xsC && q.yStride[0] == (long long)q.C * ysC && xsC > 0 && ysC > 0 &&
+           (xsC + q.xW) * esz < 0x7fffffffLL && (ysC + q.yW) * esz < 0x7fffffffLL;
+}
+
+// width of the full strips when a row is cut into full strips + a packed remainder, and their number (0: equal strips instead --
+// no remainder, a remainder too wide to pack, or more waves than equal strips take)
+constexpr int STREAM_FULL_TW = 120;
+static int stream_full_strips(int yW, int nStripsEqual) {
+    const int nFull = (yW - 1) / STREAM_FULL_TW, rem = yW - nFull * STREAM_FULL_TW;
+    return (nFull >= 1 && nFull + 1 == nStripsEqual && rem <= StreamCfg<2, 2>::PACKTW) ? nFull : 0;
+}
+
 template <typename T>
 static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
     StreamParams p;
     p.x = q.x; p.y = q.y; p.b = q.b; p.fu = q.fu; p.fd = q.fd;
-    p.C = q.C; p.xH = q.xH; p.xW = q.xW; p.yH = q.yH; p.yW = q.yW;
+    p.C = q.C; p.planes = q.N * q.C; p.xH = q.xH; p.xW = q.xW; p.yH = q.yH; p.yW = q.yW;
     p.xsN = q.xStride[0]; p.xsC = q.xStride[1]; p.xsH = q.xStride[2];
     p.ysN = q.yStride[0]; p.ysC = q.yStride[1]; p.ysH = q.yStride[2];
     p.bStride = q.bStride;
@@ -816,10 +900,41 @@ static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
     if (total > 0x7fffffffLL) { set_error("filtered_lrelu: grid too large"); return SG3_BAD_ARG; }
     p.totalBlocks = (int)total;
 
+    p.ox0Base = 0;
+    const bool packed = p.nStrips == 1 && stream_packs_planes(q, q.yW);    // the 36^2 .. 52^2 layers
+    if (packed) p.totalBlocks = (int)((planes + 1) / 2 * p.nChunks);
+    // Rows a little wider than a whole number of full strips (148 = 120 + 28, 276 = 2 x 120 + 36, 532 = 4 x 120 + 52 columns: the
+    // 148^2 .. 532^2 layers): equal strips would leave 40 .. 57 of a wave's 64 lanes at work.  Instead the full-width strips go
+    // first, one plane per wave, and the remainder strip follows in a second launch with two planes per wave:
+    // nFull + 1/2 waves per plane and row chunk instead of nFull + 1.
+    const int remFull = stream_full_strips(q.yW, p.nStrips);
+    const bool mixed = !packed && remFull > 0 && stream_packs_planes(q, q.yW - remFull * STREAM_FULL_TW);
+    // separable filters: ONE launch of the two-plane kernel, whose first blocks take the full strips (same registers as the
+    // one-plane kernel); 12x12 down filters: two launches (their two-plane kernels need 135+ registers: three waves per SIMD)
+    const bool oneLaunch = mixed && q.fdH == 0;
+    p.wideBlocks = 0;
+    if (mixed) {
+        p.nStrips = remFull; p.TW = STREAM_FULL_TW;
+        p.totalBlocks = (int)(planes * remFull * p.nChunks);
+        if (oneLaunch) {
+            p.wideBlocks = p.totalBlocks;
+            p.ox0Base = remFull * STREAM_FULL_TW;
+            const long long all = (long long)p.totalBlocks + (planes + 1) / 2 * p.nChunks;
+            if (all > 0x7fffffffLL) { set_error("filtered_lrelu: grid too large"); return SG3_BAD_ARG; }
+            p.totalBlocks = (int)all;
+        }
+    }
+
     const int vph = (((q.py0 - (q.up - 1)) % q.down) + q.down) % q.down;
-    dim3 g((unsigned)total), b(64);
+    dim3 g((unsigned)p.totalBlocks), b(64);
 #define SG3_STREAM_LAUNCH(U, D, V, R, S) hipLaunchKernelGGL((flrelu_stream_kernel<T, U, D, V, R, S>), g, b, 0, st, p)
 #define SG3_STREAM_LAUNCH_V(U, R, S) do { if (vph == 0) SG3_STREAM_LAUNCH(U, 2, 0, R, S); else SG3_STREAM_LAUNCH(U, 2, 1, R, S); } while (0)
+#define SG3_PACKED_LAUNCH(U, V, R) hipLaunchKernelGGL((flrelu_stream_kernel<T, U, 2, V, R, 0, 2>), g, b, 0, st, p)
+#define SG3_PACKED_LAUNCH_V(U, R) do { if (vph == 0) SG3_PACKED_LAUNCH(U, 0, R); else SG3_PACKED_LAUNCH(U, 1, R); } while (0)
+#define SG3_PACKED_UP(U) do { switch (variant) { \
+        case 0: SG3_PACKED_LAUNCH_V(U, 0); break; case 1: SG3_PACKED_LAUNCH_V(U, 1); break; \
+        case 2: SG3_PACKED_LAUNCH_V(U, 2); break; case 5: SG3_PACKED_LAUNCH_V(U, 5); break; \
+        default: SG3_PACKED_LAUNCH_V(U, 6); break; } } while (0)
     // separable | 12x12 | 12x12 flipped | 12x12 with mirror-symmetric rows | the same, flipped
     const int variant = q.fdH == 0 ? 0 : (q.fdMirror ? (q.flip ? 6 : 5) : (q.flip ? 2 : 1));
 #define SG3_FORWARD_UP(U, S) do { switch (variant) { \
@@ -842,9 +957,21 @@ static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
 #undef SG3_ADJOINT_LAUNCH
     } else if (q.writeSigns) {
         SG3_FORWARD_LAUNCH(1);
+    } else if (packed || oneLaunch) {
+        if (q.up == 2) SG3_PACKED_UP(2); else SG3_PACKED_UP(4);
     } else {
         SG3_FORWARD_LAUNCH(0);
+        if (mixed) {
+            SG3_LAUNCH_CHECK("flrelu_stream_kernel");
+            p.ox0Base = remFull * STREAM_FULL_TW; p.nStrips = 1; p.TW = q.yW - p.ox0Base;
+            p.totalBlocks = (int)((planes + 1) / 2 * p.nChunks);
+            g = dim3((unsigned)p.totalBlocks);
+            if (q.up == 2) SG3_PACKED_UP(2); else SG3_PACKED_UP(4);
+        }
     }
+#undef SG3_PACKED_UP
+#undef SG3_PACKED_LAUNCH_V
+#undef SG3_PACKED_LAUNCH
 #undef SG3_FORWARD_LAUNCH
 #undef SG3_FORWARD_UP
 #undef SG3_STREAM_LAUNCH_V
@@ -910,6 +1037,20 @@ int sg3_filtered_lrelu_shape(int xH, int xW, int up, int down, int fuW, int fuH,
     if (sWbytes) *sWbytes = (int)(sw >> 2);
     if (swLimit) *swLimit = (int)((sw_active + 3) >> 2);
     return SG3_OK;
+}
+
+int sg3_filtered_lrelu_planes_per_wave(const sg3_filtered_lrelu_params* p) {
+    using namespace sg3;
+    if (!p || (p->dtype != SG3_F32 && p->dtype != SG3_F16)) return 0;
+    const bool signs = p->writeSigns || p->readSigns;
+    if (!signs && pointwise_supported(p->up, p->down, p->fuW, p->fuH, p->fdW, p->fdH)) return 0;
+    if (!(stream_supported(p->up, p->down, p->fuW, p->fuH, p->fdW, p->fdH) && stream_params_ok(*p))) return 0;
+    if (p->N <= 0 || p->C <= 0 || p->yH <= 0 || p->yW <= 0) return 0;
+    int nStrips, TW, nChunks, CH;
+    stream_grid(p->N, p->C, p->yH, p->yW, p->down, nStrips, TW, nChunks, CH);
+    if (nStrips == 1) return stream_packs_planes(*p, p->yW) ? 2 : 1;
+    const int nFull = stream_full_strips(p->yW, nStrips);
+    return (nFull > 0 && stream_packs_planes(*p, p->yW - nFull * STREAM_FULL_TW)) ? 3 : 1;
 }
 
 int sg3_filtered_lrelu(const sg3_filtered_lrelu_params* p, void* stream) {

@@ -25,6 +25,7 @@
 // demodulation (dcoef) is applied in the epilogue; bias/activation belong to the following filtered_lrelu.
 #include "sg3_common.h"
 #include "sg3_split.h"
+#include <algorithm>
 #include <cstdlib>
 
 #ifndef SG3_TAILPACK
@@ -490,6 +491,194 @@ modconv_f16x3_kernel(ConvParams p) {
                     io<T>::st(outp + ((size_t)o * p.outH + gy) * p.outPitch + gx, acc[a][b][r] * d);
             }
         }
+}
+
+// ---------------------------------------------------------------------------
+// 3x3 kernel for NARROW outputs (the 36^2 .. 84^2 layers: 38 .. 86 output columns).  modconv_f16x3_kernel tiles an output row
+// into 32-column pieces, so a 38-column row fills 59 % of its two tiles.  Here the MFMA's 32 pixel columns are a run of 32
+// consecutive pixels of the FLATTENED output plane (crossing row ends), as in the 1x1 kernel: a 38 x 38 plane is 45.1 runs
+// (fill 98 %).  A workgroup (4 waves: 2 M blocks x 2 pixel groups) takes 2 TN consecutive runs; the staged patch is every input
+// row those runs touch (+ 2), full width (+ 2): at most FLAT_NPIX pixels.  Every lane keeps the patch offset of its pixel for
+// each of its TN runs; a tap adds (ky PW + kx).  No row streaming (a run's neighbours in y are not a run): tap by tap, the A
+// fragments of a tap held over the TN runs.  Same packed weights, style / demodulation handling and arithmetic as the row kernel.
+constexpr int FLAT_NPIX = 512;                 // patch pixels staged per chunk (two per thread)
+
+template <typename T, int TN, bool SPLIT>
+__global__ void __launch_bounds__(256, 2)
+modconv_flat_kernel(ConvParams p) {
+    constexpr int TAPS = 9, KC = 16;
+    constexpr int NPART = SPLIT ? 2 : 1;
+    constexpr int BM = 64, WN = 2;
+    constexpr int RUN = WN * TN * 32;                  // flat pixels per workgroup
+    constexpr int AS = TAPS * 32 + 8;
+    constexpr int AROW_V = TAPS * 32 / 8;              // 36
+    constexpr int TPR = 4;                             // threads that share one A row (64 rows)
+    constexpr int A_PER = AROW_V / TPR;                // 9
+    constexpr int BPLANE = FLAT_NPIX * 8;
+    constexpr int PX_PER = FLAT_NPIX / 256;
+
+    extern __shared__ __attribute__((aligned(16))) _Float16 smh[];
+    _Float16* sA = smh;
+    _Float16* sB = smh + BM * AS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    int bid = blockIdx.x;
+    {
+        const int nb = p.totalBlocks, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int mt = bid % p.mTiles; bid /= p.mTiles;
+    const int xt = bid % p.xTiles; const int n = bid / p.xTiles;             // xTiles = runs of RUN flat pixels per plane
+    const int o0 = mt * BM;
+    const int P = p.outH * p.outW;
+    const int f0 = xt * RUN;
+    const int ya = f0 / p.outW;                                              // first output row touched
+    const int PW = p.outW + 2;                                               // patch width: input columns -pad .. outW - pad + 1
+    const int prows = ((f0 + RUN < P ? f0 + RUN : P) - 1) / p.outW - ya + 3;  // patch rows this workgroup's runs read
+
+    const unsigned HWb = (unsigned)(p.H * p.W) * (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const T*)p.x + (size_t)n * p.I * p.H * p.W), (short)0, (int)((unsigned)p.I * HWb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.wp, (short)0, (int)((unsigned)p.O * (unsigned)p.nch * (unsigned)(AROW_V * 16)), 0x00020000);
+    const int arow = tid / TPR, acol = tid % TPR;
+    const unsigned aG = (o0 + arow < p.O) ? ((unsigned)(o0 + arow) * (unsigned)p.nch * (AROW_V * 16) + acol * 16) : 0x80000000u;
+    _Float16* aL = sA + arow * AS + acol * 8;
+    // B: thread -> PX_PER patch pixels, patch pixel e = py * PW + px <-> input (ya - pad + py, -pad + px)
+    unsigned bG[PX_PER]; int bL[PX_PER];
+#pragma unroll
+    for (int q = 0; q < PX_PER; q++) {
+        const int e = tid + 256 * q;
+        const int py = e / PW, px = e - py * PW;
+        const int gy = ya - p.pad + py, gx = px - p.pad;
+        const bool ok = py < prows && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        bG[q] = ok ? (unsigned)(gy * p.W + gx) * (unsigned)sizeof(T) : 0x80000000u;
+        bL[q] = e * 8;
+    }
+    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.sIn + (size_t)n * p.I), (short)0, p.I * 4, 0x00020000);
+    float rsc;
+    // this lane's pixel in each of its TN runs: patch offset (halfs) and flat index
+    int pb[TN], pf[TN];
+#pragma unroll
+    for (int b = 0; b < TN; b++) {
+        const int f = f0 + (wn * TN + b) * 32 + li;
+        const int y = f / p.outW, x = f - y * p.outW;
+        pf[b] = f < P ? f : -1;
+        pb[b] = f < P ? ((y - ya) * PW + x) * 8 : 0;                          // runs beyond the plane read pixel 0 and are not stored
+    }
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int b = 0; b < TN; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[b][r] = 0.f;
+    u32x4 ra[A_PER];
+    float rb[PX_PER][2][8];
+
+    auto fetch = [&](int ch) {
+        rsc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, (ch * KC + (lane & 15)) * 4, 0, 0));
+        const unsigned aoff = aG + (unsigned)ch * (AROW_V * 16);
+#pragma unroll
+        for (int q = 0; q < A_PER; q++) ra[q] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)(aoff + q * TPR * 16), 0, 0);
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int ci = ch * KC + hf * 8 + c;                        // wave-uniform
+                const unsigned coff = ci < p.I ? (unsigned)ci * HWb : 0u;
+#pragma unroll
+                for (int q = 0; q < PX_PER; q++) rb[q][hf][c] = bufld<T>::ld(xr, bG[q], coff);
+            }
+    };
+    auto stage = [&]() {
+        float sc[2][8];
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+            for (int c = 0; c < 8; c++)
+                sc[hf][c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rsc), hf * 8 + c));
+#pragma unroll
+        for (int q = 0; q < A_PER; q++) *reinterpret_cast<u32x4*>(aL + q * TPR * 8) = ra[q];
+#pragma unroll
+        for (int q = 0; q < PX_PER; q++)
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                v2h h[4], l[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float v0 = rb[q][hf][2 * c] * sc[hf][2 * c], v1 = rb[q][hf][2 * c + 1] * sc[hf][2 * c + 1];
+                    if (SPLIT) split2(v0, v1, h[c], l[c]);
+                    else h[c] = round2(v0, v1);
+                }
+                _Float16* dst = sB + (hf * NPART) * BPLANE + bL[q];
+                *reinterpret_cast<v8h*>(dst) = __builtin_shufflevector(__builtin_shufflevector(h[0], h[1], 0, 1, 2, 3), __builtin_shufflevector(h[2], h[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
+                if (SPLIT)
+                    *reinterpret_cast<v8h*>(dst + BPLANE) = __builtin_shufflevector(__builtin_shufflevector(l[0], l[1], 0, 1, 2, 3), __builtin_shufflevector(l[2], l[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+    };
+
+    const int oL = o0 + wm * 32 + 4 * lh;
+    float d[16];
+    {
+        const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dcoef + (size_t)n * p.O), (short)0, p.O * 4, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            d[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, (oL + (r & 3) + 8 * (r >> 2)) * 4, 0, 0));
+    }
+    const _Float16* aBase = sA + (wm * 32 + li) * AS + lh * 8;
+    const _Float16* bBase = sB + (lh * NPART) * BPLANE;
+
+    fetch(0);
+    for (int ch = 0; ch < p.nch; ch++) {
+        __syncthreads();
+        stage();
+        __syncthreads();
+        if (ch + 1 < p.nch) fetch(ch + 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; tap++) {
+            const int toff = ((tap / 3) * PW + tap % 3) * 8;                 // wave-uniform
+            const v8h ah = *reinterpret_cast<const v8h*>(aBase + tap * 32);
+            v8h al;
+            if (SPLIT) al = *reinterpret_cast<const v8h*>(aBase + tap * 32 + 16);
+#pragma unroll
+            for (int b = 0; b < TN; b++) {
+                const _Float16* src = bBase + pb[b] + toff;
+                const v8h bh = *reinterpret_cast<const v8h*>(src);
+                if (SPLIT) {
+                    const v8h bl = *reinterpret_cast<const v8h*>(src + BPLANE);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
+                }
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    // the runs are contiguous in the dense output plane: 128-byte store segments
+    T* outp = (T*)p.out + (size_t)n * p.O * P;
+    const unsigned planeB = (unsigned)P * (unsigned)sizeof(T);
+    const bool desc = (unsigned long long)(p.mTiles * BM + 32) * planeB < 0x7fffffffULL;
+    const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)outp, (short)0, desc ? (int)((unsigned)p.O * planeB) : 0, 0x00020000);
+#pragma unroll
+    for (int b = 0; b < TN; b++) {
+        const unsigned base = pf[b] >= 0 ? (unsigned)oL * planeB + (unsigned)pf[b] * (unsigned)sizeof(T) : 0x80000000u;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int orow = (r & 3) + 8 * (r >> 2);
+            const float v = acc[b][r] * d[r];
+            if (desc) {
+                if (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orr, (int)(base + (unsigned)orow * planeB), 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), orr, (int)(base + (unsigned)orow * planeB), 0, 0);
+            } else if (pf[b] >= 0 && oL + orow < p.O) {
+                io<T>::st(outp + (size_t)(oL + orow) * P + pf[b], v);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1077,6 +1266,38 @@ static int launch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     return SG3_OK;
 }
 
+// SG3_CONV3_ROWS=1 in the environment keeps the narrow 3x3 layers on the row-tile kernel (A/B timing; read once)
+static bool conv3_use_flat() {
+    static const bool v = [] { const char* e = getenv("SG3_CONV3_ROWS"); return !(e && e[0] == '1'); }();
+    return v;
+}
+
+// does the patch of every RUN-pixel piece of an outH x outW plane fit FLAT_NPIX pixels?  rows touched <= (RUN - 2) / outW + 2
+static bool flat_fits(int outW, int run) { return ((run - 2) / outW + 2 + 2) * (outW + 2) <= FLAT_NPIX; }
+
+template <typename T, int TN, bool SPLIT>
+static int launch_conv_flat(const sg3_modconv_params& q, hipStream_t st) {
+    constexpr int RUN = 2 * TN * 32;
+    constexpr size_t ldsBytes = ((size_t)64 * (9 * 32 + 8) + (SPLIT ? 4 : 2) * (size_t)FLAT_NPIX * 8) * sizeof(_Float16);
+    static_assert(ldsBytes <= 80 * 1024, "two workgroups per CU");
+    ConvParams p;
+    p.x = q.x; p.wp = q.wPacked; p.sIn = q.sIn; p.dcoef = q.dcoef; p.out = q.out;
+    p.N = q.N; p.I = q.I; p.O = q.O; p.H = q.H; p.W = q.W; p.pad = q.pad;
+    p.outH = q.H + 2 * q.pad - 2; p.outW = q.W + 2 * q.pad - 2;
+    p.nch = ceil_div(q.I, 16);
+    p.xTiles = ceil_div(p.outH * p.outW, RUN); p.yTiles = 1; p.mTiles = ceil_div(q.O, 64);
+    const long long total = (long long)p.xTiles * p.mTiles * q.N;
+    if (total > 0x7fffffffLL) { set_error("modulated_conv2d: grid too large"); return SG3_BAD_ARG; }
+    p.totalBlocks = (int)total;
+    p.outPitch = p.outW; p.tailPack = 0;
+    auto kern = modconv_flat_kernel<T, TN, SPLIT>;
+    if (ldsBytes > 64 * 1024)
+        SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), ldsBytes, st, p);
+    SG3_LAUNCH_CHECK("modconv_flat_kernel");
+    return SG3_OK;
+}
+
 template <typename T, bool SPLIT>
 static int dispatch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     // Two row-streaming tiles, two workgroups per CU each.  The 64-channel tile stages the patch once for twice the
@@ -1089,6 +1310,25 @@ static int dispatch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     const bool pack = SG3_TAILPACK && q.I > 16 && q.I % 16 >= 1 && q.I % 16 <= 4;
     if (O <= 32 || t32 * 10 <= t64 * 9)                                                            //  32 x (16 rows x 32)
         return pack ? launch_conv_f16x3<T, 1, 4, 4, SPLIT, true>(q, st) : launch_conv_f16x3<T, 1, 4, 4, SPLIT, false>(q, st);
+    // Narrow outputs with 64-channel tiles: runs of the flattened plane instead of 32-column row pieces (modconv_flat_kernel) when
+    // that takes fewer rounds x MFMA blocks per wave than the best row tile.  SG3_CONV3_ROWS=1 keeps the row kernel.
+    if (!pack && (q.outRowStride == 0 || q.outRowStride == q.W + 2 * q.pad - 2) && conv3_use_flat()) {
+        const int outH = q.H + 2 * q.pad - 2, outW = q.W + 2 * q.pad - 2;
+        const long long perM = (long long)q.N * ceil_div(O, 64);
+        // time ~ rounds of 512 resident workgroups x (blocks per wave + staging); large grids are not quantised
+        auto cost = [](long long wgs, int tn) { return (wgs <= 2048 ? (double)ceil_div64(wgs, 512) : wgs / 512.0) * (tn + 0.5); };
+        const long long perRow = perM * ceil_div(outW, 32);
+        const double rowCost = std::min(cost(perRow * ceil_div(outH, 8), 4), cost(perRow * ceil_div(outH, 10), 5));
+        int best = 0; double bestCost = rowCost * 0.9;                       // the row kernel reads less LDS per MFMA: flat must save 10 %
+        for (int tn = 4; tn >= 2; tn--) {
+            if (!flat_fits(outW, 64 * tn)) continue;
+            const double c = cost(perM * ceil_div(outH * outW, 64 * tn), tn);
+            if (c < bestCost) { bestCost = c; best = tn; }
+        }
+        if (best == 4) return launch_conv_flat<T, 4, SPLIT>(q, st);
+        if (best == 3) return launch_conv_flat<T, 3, SPLIT>(q, st);
+        if (best == 2) return launch_conv_flat<T, 2, SPLIT>(q, st);
+    }
     if (!pack) {
         // Small grids (the 36^2 .. 52^2 layers): 512 workgroups are resident at once, so the time goes with the number of
         // ROUNDS times the rows a workgroup computes.  Ten-row tiles turn the 640 workgroups of a 38-row output (8 images

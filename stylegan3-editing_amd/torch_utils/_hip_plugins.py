@@ -18,6 +18,7 @@ import torch
 from . import _sg3abi as abi
 
 INT_MAX = 2 ** 31 - 1
+planes_per_wave_log = None      # set to a list to record sg3_filtered_lrelu_planes_per_wave of every filtered_lrelu call
 
 
 def _require(cond, msg):
@@ -112,6 +113,8 @@ class FilteredLreluPlugin:
             if slots > 0:
                 partial = torch.empty([N, C, slots], dtype=torch.float32, device=x.device)
                 p.ySumPartial = abi.ptr(partial)
+        if planes_per_wave_log is not None:            # tests: which form of the streaming kernel this call takes (host-only query)
+            planes_per_wave_log.append(int(lib.sg3_filtered_lrelu_planes_per_wave(ctypes.byref(p))))
         with torch.cuda.device(x.device):
             rc = lib.sg3_filtered_lrelu(ctypes.byref(p), abi.stream_ptr(x.device))
         if abi.check(rc, 'sg3_filtered_lrelu', allow_no_kernel=True) == abi.SG3_NO_KERNEL:

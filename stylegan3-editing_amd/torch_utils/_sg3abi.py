@@ -86,6 +86,7 @@ EXPORTS = [
     ('sg3_last_error', ctypes.c_char_p, []),
     ('sg3_device_count', ctypes.c_int, []),
     ('sg3_filtered_lrelu', ctypes.c_int, [ctypes.POINTER(FilteredLreluParams), c_vp]),
+    ('sg3_filtered_lrelu_planes_per_wave', ctypes.c_int, [ctypes.POINTER(FilteredLreluParams)]),
     ('sg3_filtered_lrelu_has_kernel', ctypes.c_int, [ctypes.c_int] * 6),
     ('sg3_filtered_lrelu_sum_slots', ctypes.c_int, [ctypes.c_int] * 5),
     ('sg3_filtered_lrelu_shape', ctypes.c_int, [ctypes.c_int] * 12 + [ctypes.POINTER(ctypes.c_int)] * 5),

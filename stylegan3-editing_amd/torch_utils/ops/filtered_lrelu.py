@@ -167,11 +167,11 @@ class _FusedFlrelu(torch.autograd.Function):
                 # first-order gradients: the fused adjoint kernel also accumulates the per-channel sum of dx, so the
                 # bias gradient needs no second pass over dx
                 zero_b = torch.zeros([dy.shape[1]], dtype=dy.dtype, device=dy.device)
-                out, _, code, csum = _plugin.filtered_lrelu(dy.contiguous(), fd, fu, zero_b, signs, adj.up, adj.down,
-                                                            adj.px0, adj.px1, adj.py0, adj.py1, sx, sy, adj.gain, adj.slope,
-                                                            adj.clamp, adj.flip, False, return_sum=want_b)
-                if code == 0:
-                    dx, db = out, (csum if want_b else None)
+                res = _plugin.filtered_lrelu(dy.contiguous(), fd, fu, zero_b, signs, adj.up, adj.down,
+                                             adj.px0, adj.px1, adj.py0, adj.py1, sx, sy, adj.gain, adj.slope,
+                                             adj.clamp, adj.flip, False, return_sum=want_b)
+                if res[2] == 0:                     # (y, signs, code) and, with return_sum, the per-channel sums
+                    dx, db = res[0], (res[3] if want_b else None)
             if dx is None:
                 dx = _FusedFlrelu.apply(dy, fd, fu, None, adj, signs, sx, sy)
             if want_b and db is None:

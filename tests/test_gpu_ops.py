@@ -638,3 +638,154 @@ def test_modulated_conv2d_aligned_row_pitch(n, ci, co, h):
     # with gradients recorded the request is ignored (the autograd graph keeps dense tensors)
     xg = x.clone().requires_grad_(True)
     assert modulated_conv.modulated_conv2d(xg, w, s, demodulate=True, padding=2, x_bound=8.0, align_rows=True).is_contiguous()
+
+
+class _planes_per_wave:
+    """Records, for every filtered_lrelu call inside the block, how many planes a wave of the streaming kernel works on."""
+
+    def __enter__(self):
+        from torch_utils import _hip_plugins
+        _hip_plugins.planes_per_wave_log = self.log = []
+        return self.log
+
+    def __exit__(self, *exc):
+        from torch_utils import _hip_plugins
+        _hip_plugins.planes_per_wave_log = None
+
+
+@pytest.mark.parametrize('shape,up,taps,pad,radial', [
+    ((8, 6, 38, 38), 2, 12, [9, 8, 9, 8], False),          # T L0 / L1: 36 columns out
+    ((2, 4, 38, 38), 4, 24, [-6, -9, -6, -9], False),      # T L2: up 4, 52 columns out
+    ((1, 2, 54, 54), 2, 12, [9, 8, 9, 8], False),          # T L3: 52 columns out
+    ((3, 2, 41, 56), 2, 12, [9, 8, 9, 8], False),          # 54 columns: the widest packed row; more rows than columns of lanes
+    ((1, 4, 30, 39), 2, 12, [8, 8, 9, 8], False),          # odd output width (single stores), odd horizontal phase
+    ((2, 2, 33, 27), 4, 24, [-5, -8, -6, -9], False),      # up 4 with the strip shifted by three upsampled columns
+    ((2, 4, 36, 36), 2, 12, [11, 10, 11, 10], True),       # R: radial down filter, up 2
+    ((1, 2, 36, 36), 4, 24, [-2, -5, -2, -5], True),       # R: radial, up 4
+])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_filtered_lrelu_two_planes_per_wave(shape, up, taps, pad, radial, dtype):
+    """Narrow planes (output at most 54 columns): one wave works on two planes, 32 lanes each.  Same oracle, same tolerances as the
+    one-plane form; the host query tells which form ran, so the case cannot pass on the other one."""
+    from oracle import oracle as O
+    fu = O.design_lowpass_filter(taps, 4.0, 8.0, 64.0 * up / 2)
+    fd = O.design_lowpass_filter(12, 5.0, 9.0, 64.0, radial=radial)
+    if radial:
+        fd = (fd + 0.01 * np.random.RandomState(8).rand(12, 12)).astype(np.float32)      # symmetry broken: exposes flips
+    x = rand(3, *shape); b = rand(4, shape[1])
+    if dtype == torch.float16:
+        x = x.astype(np.float16).astype(np.float32); b = b.astype(np.float16).astype(np.float32)
+    for flip in ((False, True) if radial else (False,)):
+        c = dict(up=up, down=2, padding=pad, gain=float(np.sqrt(2)), slope=0.2, clamp=256, flip=flip)
+        with _planes_per_wave() as log:
+            y = _flrelu(c, T(x, dtype), T(b, dtype), T(fu), T(fd))
+        assert log == [2]
+        ref = O.filtered_lrelu(x, fu, fd, b, up, 2, pad, c['gain'], 0.2, 256, flip)
+        assert tuple(y.shape) == ref.shape and ref.shape[3] <= 54
+        assert maxabs(y.float().cpu().numpy(), ref) <= (2e-5 if dtype == torch.float32 else 4e-3)
+
+
+def test_filtered_lrelu_two_planes_per_wave_only_where_it_applies():
+    """Wider rows, sliced (non-dense) planes and the training / adjoint forms keep one plane per wave; odd channel and plane
+    counts pack.  All agree with the oracle."""
+    from oracle import oracle as O
+    fu = O.design_lowpass_filter(12, 4.0, 8.0, 64.0)
+    fd = O.design_lowpass_filter(12, 5.0, 9.0, 64.0)
+    c = dict(up=2, down=2, padding=[9, 8, 9, 8], gain=float(np.sqrt(2)), slope=0.2, clamp=256, flip=False)
+
+    def check(xt, bt, xn, bn, expect):
+        with _planes_per_wave() as log:
+            y = _flrelu(c, xt, bt, T(fu), T(fd))
+        assert log == [expect], (log, expect)
+        assert maxabs(y.cpu().numpy(), O.filtered_lrelu(xn, fu, fd, bn, 2, 2, c['padding'], c['gain'], 0.2, 256, False)) <= 2e-5
+
+    x = rand(3, 2, 4, 38, 38); b = rand(4, 4)
+    check(T(x), T(b), x, b, 2)
+    x3 = rand(5, 2, 3, 38, 38); b3 = rand(6, 3)
+    check(T(x3), T(b3), x3, b3, 2)                                                   # odd C: one wave's planes straddle two images
+    check(T(x3[:1]), T(b3), x3[:1], b3, 2)                                           # three planes: the last wave has a single one
+    check(T(x)[:, 1:3], T(b)[1:3], np.ascontiguousarray(x[:, 1:3]), b[1:3].copy(), 1)   # channel slice: planes not dense over (n, c)
+    big = rand(7, 2, 4, 40, 44)
+    check(T(big)[:, :, 1:39, 3:41], T(b), np.ascontiguousarray(big[:, :, 1:39, 3:41]), b, 2)   # row-padded view: still dense over (n, c)
+    xw = rand(8, 1, 2, 38, 60); bw = rand(9, 2)
+    check(T(xw), T(bw), xw, bw, 1)                                                   # 58 columns out: too wide for 32 lanes
+    xt = T(x).requires_grad_(True)                                                   # training forward writes signs: one plane
+    with _planes_per_wave() as log:
+        y = _flrelu(c, xt, T(b), T(fu), T(fd))
+        y.sum().backward()
+    assert log and all(v == 1 for v in log)
+    # x alone requires a gradient above (the bias does not): same dx as when both do
+    x2, b2 = T(x).requires_grad_(True), T(b).requires_grad_(True)
+    _flrelu(c, x2, b2, T(fu), T(fd)).sum().backward()
+    assert torch.equal(xt.grad, x2.grad) and b2.grad is not None
+
+
+def test_filtered_lrelu_two_planes_per_wave_non_finite_input():
+    """The NaN contract of the one-plane form, per plane: the plane that holds a NaN / infinity goes NaN from that row on, the
+    plane sharing its wave is bit-for-bit what it is without it."""
+    from oracle import oracle as O
+    from torch_utils.ops import filtered_lrelu as fl
+    fu = O.design_lowpass_filter(12, 4.0, 8.0, 64.0)
+    fd = O.design_lowpass_filter(12, 5.0, 9.0, 64.0)
+    clean = rand(3, 1, 6, 38, 54); b = rand(4, 6)
+    x = clean.copy()
+    x[0, 0, 20, 30] = np.nan              # first plane of wave 0 (its partner, plane 1, stays clean)
+    x[0, 3, 25, 2] = np.inf               # second plane of wave 1 (plane 2 stays clean)
+    x[0, 5, 10, 53] = np.nan              # last input column of the second plane of wave 2: staged by the third load of a row
+    kw = dict(up=2, down=2, padding=[9, 8, 9, 8], gain=float(np.sqrt(2)), slope=0.2, clamp=256, flip_filter=False)
+    with _planes_per_wave() as log:
+        y = fl.filtered_lrelu(T(x), T(fu), T(fd), T(b), **kw).cpu().numpy()
+        y_clean = fl.filtered_lrelu(T(clean), T(fu), T(fd), T(b), **kw).cpu().numpy()
+    assert log == [2, 2]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        ref = fl.filtered_lrelu(torch.from_numpy(x), torch.from_numpy(fu), torch.from_numpy(fd), torch.from_numpy(b), impl='ref', **kw).numpy()
+    assert np.isfinite(y_clean).all()
+    assert np.isnan(y[np.isnan(ref)]).all()
+    for plane in (1, 2, 4):
+        assert np.array_equal(y[0, plane], y_clean[0, plane])
+    for plane in (0, 3, 5):
+        first = int(np.argmax(np.isnan(y[0, plane]).any(axis=1)))
+        assert first > 0 and np.isnan(y[0, plane, first:]).all() and np.array_equal(y[0, plane, :first], y_clean[0, plane, :first])
+
+
+@pytest.mark.parametrize('shape,up,taps,pad,radial', [
+    ((2, 2, 150, 150), 2, 12, [9, 8, 9, 8], False),        # T L6: 148 columns = 120 + 28
+    ((1, 4, 86, 86), 4, 24, [-6, -9, -6, -9], False),      # T L5: up 4, 148 columns
+    ((1, 2, 60, 278), 4, 24, [-6, -9, -6, -9], False),     # T L9-like rows: 532 columns = 4 x 120 + 52
+    ((1, 2, 100, 150), 2, 12, [11, 10, 11, 10], True),     # R: radial down filter
+])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_filtered_lrelu_full_strips_plus_packed_remainder(shape, up, taps, pad, radial, dtype):
+    """Rows a little wider than a whole number of 120-column strips: the full strips run one plane per wave, the remainder strip
+    (at most 54 columns) two planes per wave in a second launch.  Same oracle and tolerances."""
+    from oracle import oracle as O
+    fu = O.design_lowpass_filter(taps, 4.0, 8.0, 64.0 * up / 2)
+    fd = O.design_lowpass_filter(12, 5.0, 9.0, 64.0, radial=radial)
+    if radial:
+        fd = (fd + 0.01 * np.random.RandomState(8).rand(12, 12)).astype(np.float32)
+    x = rand(3, *shape); b = rand(4, shape[1])
+    if dtype == torch.float16:
+        x = x.astype(np.float16).astype(np.float32); b = b.astype(np.float16).astype(np.float32)
+    c = dict(up=up, down=2, padding=pad, gain=float(np.sqrt(2)), slope=0.2, clamp=256, flip=False)
+    with _planes_per_wave() as log:
+        y = _flrelu(c, T(x, dtype), T(b, dtype), T(fu), T(fd))
+    assert log == [3]
+    ref = O.filtered_lrelu(x, fu, fd, b, up, 2, pad, c['gain'], 0.2, 256, False)
+    assert tuple(y.shape) == ref.shape
+    assert maxabs(y.float().cpu().numpy(), ref) <= (2e-5 if dtype == torch.float32 else 4e-3)
+    # a NaN under the remainder strip: its plane goes NaN there from that row on; the full strip of the same plane and the plane
+    # sharing the wave stay bit-for-bit clean
+    if dtype == torch.float32 and not radial:
+        xn = x.copy()
+        xn[0, 1, shape[2] // 2, shape[3] - 3] = np.nan
+        yn = _flrelu(c, T(xn), T(b), T(fu), T(fd)).cpu().numpy()
+        yc = y.cpu().numpy()
+        full = (yc.shape[3] - 1) // 120 * 120
+        nan = np.isnan(yn)
+        rows = nan[0, 1].any(axis=1)
+        first = int(np.argmax(rows))
+        assert first > 0 and nan[0, 1, first, full:].all()           # the whole width of the remainder strip, from the NaN's row on
+        assert not nan[0, 1, :, :full].any() and not nan[0, 0].any() and not nan[1:].any()
+        assert np.array_equal(yn[~nan], yc[~nan])
