@@ -909,9 +909,10 @@ static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
     // nFull + 1/2 waves per plane and row chunk instead of nFull + 1.
     const int remFull = stream_full_strips(q.yW, p.nStrips);
     const bool mixed = !packed && remFull > 0 && stream_packs_planes(q, q.yW - remFull * STREAM_FULL_TW);
-    // separable filters: ONE launch of the two-plane kernel, whose first blocks take the full strips (same registers as the
-    // one-plane kernel); 12x12 down filters: two launches (their two-plane kernels need 135+ registers: three waves per SIMD)
-    const bool oneLaunch = mixed && q.fdH == 0;
+    // ONE launch of the two-plane kernel, whose first blocks take the full strips, where it holds as many waves per SIMD as the
+    // one-plane kernel (separable: 120 / 124 registers at up 2, 142 / 144 at up 4; 12x12 down filter at up 4: 153 .. 160 against
+    // 148 .. 156, three waves either way).  12x12 down filter at up 2: two launches (135 registers against 128: three waves, not four)
+    const bool oneLaunch = mixed && (q.fdH == 0 || q.up == 4);
     p.wideBlocks = 0;
     if (mixed) {
         p.nStrips = remFull; p.TW = STREAM_FULL_TW;

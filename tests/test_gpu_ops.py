@@ -754,7 +754,8 @@ def test_filtered_lrelu_two_planes_per_wave_non_finite_input():
     ((2, 2, 150, 150), 2, 12, [9, 8, 9, 8], False),        # T L6: 148 columns = 120 + 28
     ((1, 4, 86, 86), 4, 24, [-6, -9, -6, -9], False),      # T L5: up 4, 148 columns
     ((1, 2, 60, 278), 4, 24, [-6, -9, -6, -9], False),     # T L9-like rows: 532 columns = 4 x 120 + 52
-    ((1, 2, 100, 150), 2, 12, [11, 10, 11, 10], True),     # R: radial down filter
+    ((1, 2, 100, 150), 2, 12, [11, 10, 11, 10], True),     # R: radial down filter, up 2 (two launches)
+    ((1, 3, 60, 84), 4, 24, [-2, -5, -2, -5], True),       # R L5: radial, up 4 (one launch), odd plane count
 ])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
 def test_filtered_lrelu_full_strips_plus_packed_remainder(shape, up, taps, pad, radial, dtype):
