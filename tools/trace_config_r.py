@@ -11,22 +11,33 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 sel = [r for r in rows if 'sg3::' in r['Kernel_Name'] and 'prep' not in r['Kernel_Name'] and 'fourier' not in r['Kernel_Name']]
-# the ToRGB layer's filtered_lrelu rides in its convolution in inference: the forward then ends with a convolution
-sel = sel[-29:] if 'modconv' in sel[-1]['Kernel_Name'] else sel[-30:]
-ci = fi = 0
-tc = tf = 0.0
+# The last forward: 15 convolutions (+ the input's channel mix) back from the end.  A layer's filtered_lrelu may be two launches
+# (12x12 down filter at up 2 on 148- / 276-column rows: full strips, then the packed remainder strip); the ToRGB layer's rides
+# in its convolution in inference.
+groups = []                                   # [is_conv, name, duration us]
 for r in sel:
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    n = r['Kernel_Name']
-    if 'modconv' in n:
+    conv = 'modconv' in r['Kernel_Name']
+    if groups and not conv and not groups[-1][0]:
+        groups[-1][2] += d; groups[-1][1] += ' + remainder launch'
+    else:
+        groups.append([conv, r['Kernel_Name'][10:52], d])
+n_conv, start = 0, len(groups)
+while start > 0 and n_conv < 15:
+    start -= 1
+    n_conv += groups[start][0]
+ci = fi = 0
+tc = tf = 0.0
+for conv, n, d in groups[start:]:
+    if conv:
         i, o, s, _ = LAYERS[ci]
         fl = 2.0 * i * o * s * s * B
         by = 4.0 * (i + o) * s * s * B
-        print(f"conv L{ci:<2d} {i:4d}->{o:4d} @{s:4d}  {n[10:52]:42s} {d:8.1f} us {fl / d / 1e6:7.1f} TF/s {by / d / 1e6:6.2f} TB/s")
+        print(f"conv L{ci:<2d} {i:4d}->{o:4d} @{s:4d}  {n:42s} {d:8.1f} us {fl / d / 1e6:7.1f} TF/s {by / d / 1e6:6.2f} TB/s")
         ci += 1; tc += d
     else:
         i, o, s, so = LAYERS[fi]
         by = 4.0 * o * (s * s + so * so) * B
-        print(f"flr  L{fi:<2d} {o:4d} ch {s:4d}->{so:4d}  {n[10:52]:42s} {d:8.1f} us {by / d / 1e6:6.2f} TB/s")
+        print(f"flr  L{fi:<2d} {o:4d} ch {s:4d}->{so:4d}  {n:42s} {d:8.1f} us {by / d / 1e6:6.2f} TB/s")
         fi += 1; tf += d
 print(f'conv total {tc / 1e3:.2f} ms   flrelu total {tf / 1e3:.2f} ms')
