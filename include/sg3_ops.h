@@ -238,6 +238,51 @@ typedef struct sg3_fourier_params {
 SG3_API int sg3_fourier_features(const sg3_fourier_params* p, void* stream);
 
 /* ------------------------------------------------------------------------
+ * input_transform -- the per-sample frequencies / phases / amplitudes of
+ *   SynthesisInput.forward (models/stylegan3/networks_stylegan3.py:204-230): t' = t / |t[:2]| (when `normalise`; :206),
+ *   M = R(t') @ T(t') @ user (:213-221), phases + freqs @ M[:2,2:], freqs @ M[:2,:2] (:224-225), amplitude fade-out (:228).
+ *   One launch instead of ~35 small torch ops; products are formed k-ascending with one rounding per step like the
+ *   reference's fp32 matmuls (differences, if any, are single roundings).  float32.
+ * ---------------------------------------------------------------------- */
+typedef struct sg3_input_transform_params {
+    const float*   t;          /* [N,4] affine output (r_c, r_s, t_x, t_y) */
+    const float*   user;       /* [3,3] (userStrideN = 0) or [N,3,3] (userStrideN = 9): SynthesisInput.transform */
+    const float*   freqs;      /* [C,2] */
+    const float*   phases;     /* [C] */
+    float*         outFreqs;   /* [N,C,2] */
+    float*         outPhases;  /* [N,C] */
+    float*         outAmps;    /* [N,C] */
+    int32_t        N, C;
+    int32_t        normalise;  /* 1: divide t by |t[:2]| first (t straight from the affine layer) */
+    int32_t        userStrideN;
+    float          bandwidth, samplingRate;
+} sg3_input_transform_params;
+
+SG3_API int sg3_input_transform(const sg3_input_transform_params* p, void* stream);
+
+/* ------------------------------------------------------------------------
+ * affine_batch -- the affine layers (FullyConnectedLayer, linear activation) of every synthesis layer in one launch:
+ *   out_j[n, i] = (ws[n, wsIndex[j], :] . weight[rowStart[j] + i, :] + bias[rowStart[j] + i]) * scale[rowStart[j] + i]
+ *   (networks_stylegan3.py:88-96 per layer, called at :205 and :349; the ToRGB gain of :350-352 is `scale`).
+ *   `weight` holds all layers' matrices one after the other with weight_gain already applied (`weight * weight_gain`, one
+ *   rounding, as :89), `bias` likewise (`bias * bias_gain`).  Layer j's result is the dense block [N, C_j] at
+ *   out + N * rowStart[j].  float32; the dot product is accumulated in another order than the BLAS call's (1e-7 relative).
+ * ---------------------------------------------------------------------- */
+typedef struct sg3_affine_batch_params {
+    const float*   ws;         /* latents: element (n, l, k) at ws[n * wsStrideN + l * wsStrideL + k] */
+    int64_t        wsStrideN, wsStrideL;
+    const float*   weight;     /* [rows, wDim] */
+    const float*   bias;       /* [rows] or NULL */
+    const float*   scale;      /* [rows] or NULL (= 1) */
+    const int32_t* rowStart;   /* [layers + 1] DEVICE array: first row of each layer, rowStart[layers] = rows */
+    const int32_t* wsIndex;    /* [layers] DEVICE array: which latent each layer reads */
+    float*         out;        /* [N * rows] */
+    int32_t        N, wDim, layers, rows;
+} sg3_affine_batch_params;
+
+SG3_API int sg3_affine_batch(const sg3_affine_batch_params* p, void* stream);
+
+/* ------------------------------------------------------------------------
  * modulated_conv2d -- replaces the grouped F.conv2d behind
  *   models/stylegan3/networks_stylegan3.py:24-63 (modulated_conv2d), reached
  *   through torch_utils/ops/conv2d_gradfix.py:36-39.
@@ -300,6 +345,8 @@ typedef struct sg3_modconv_prep_params {
                                 * demodulation) carries the inverse */
     const float*   xBoundDev;  /* optional DEVICE pointer to that bound (overrides xBound when not NULL): lets a caller
                                 * derive it on the device, e.g. max |dy| of a gradient, without a host round trip */
+    int32_t        reuseWeights; /* 1: wPacked and wsq already hold the result of an earlier call with the same w, k, precision
+                                  * and demodulate (inference with unchanged weights): only the style pass (sIn, dcoef) runs */
 } sg3_modconv_prep_params;
 
 SG3_API int sg3_modulated_conv2d_prep(const sg3_modconv_prep_params* p, void* stream);

@@ -1437,12 +1437,14 @@ int sg3_modulated_conv2d_prep_batch(const sg3_modconv_prep_params* list, int cou
             const int gy = std::min(16, ceil_div(p->O, 32));
             bw.p[j] = bs.p[j] = *p;
             bw.kc[j] = bs.kc[j] = kc; bw.nch[j] = bs.nch[j] = nch; bw.gy[j] = bs.gy[j] = gy;
-            bw.first[j + 1] = bw.first[j] + p->O;
+            bw.first[j + 1] = bw.first[j] + (p->reuseWeights ? 0 : p->O);        // an entry whose packed weights stand takes no workgroup
             bs.first[j + 1] = bs.first[j] + p->N * gy;
             lds = std::max(lds, (size_t)p->I * 2 * sizeof(float));
         }
-        hipLaunchKernelGGL(modconv_prep_w_batch_kernel, dim3(bw.first[m]), dim3(256), 0, st, bw);
-        SG3_LAUNCH_CHECK("modconv_prep_w_batch_kernel");
+        if (bw.first[m] > 0) {
+            hipLaunchKernelGGL(modconv_prep_w_batch_kernel, dim3(bw.first[m]), dim3(256), 0, st, bw);
+            SG3_LAUNCH_CHECK("modconv_prep_w_batch_kernel");
+        }
         hipLaunchKernelGGL(modconv_prep_s_batch_kernel, dim3(bs.first[m]), dim3(256), lds, st, bs);
         SG3_LAUNCH_CHECK("modconv_prep_s_batch_kernel");
     }
@@ -1455,8 +1457,10 @@ int sg3_modulated_conv2d_prep(const sg3_modconv_prep_params* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int kc = packed_kc(p->k);
     const int nch = p->precision != SG3_CONV_FP32 ? f16x3_chunks(p->I, p->k) : ceil_div(p->I, kc);
-    hipLaunchKernelGGL(modconv_prep_w_kernel, dim3(p->O), dim3(256), 0, st, *p, kc, nch);
-    SG3_LAUNCH_CHECK("modconv_prep_w_kernel");
+    if (!p->reuseWeights) {
+        hipLaunchKernelGGL(modconv_prep_w_kernel, dim3(p->O), dim3(256), 0, st, *p, kc, nch);
+        SG3_LAUNCH_CHECK("modconv_prep_w_kernel");
+    }
     hipLaunchKernelGGL(modconv_prep_s_kernel, dim3(p->N, min(16, ceil_div(p->O, 32))), dim3(256), (size_t)p->I * 2 * sizeof(float), st, *p);
     SG3_LAUNCH_CHECK("modconv_prep_s_kernel");
     return SG3_OK;

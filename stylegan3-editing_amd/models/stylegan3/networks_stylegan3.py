@@ -18,6 +18,7 @@ Small dense algebra that the reference also leaves to the BLAS library (the 512-
 the 36x36 Fourier-feature GEMM) stays on torch ops.
 """
 import collections
+import weakref
 
 import numpy as np
 import scipy.signal
@@ -25,8 +26,20 @@ import scipy.special
 import torch
 
 from torch_utils import misc, persistence
-from torch_utils.ops import bias_act, filtered_lrelu, fourier_features
+from torch_utils.ops import affine_batch, bias_act, filtered_lrelu, fourier_features
 from torch_utils.ops import modulated_conv as _modconv
+
+# Inference-time constants derived from parameters (scaled affine weights, the input's sampling grid and mixing matrix, the
+# layers' input gains), kept per module OUTSIDE the module's __dict__ so that they are neither pickled nor deep-copied with it;
+# every entry carries the `(data_ptr, _version)` of the parameters it was made from and is rebuilt when those change.
+_derived = weakref.WeakKeyDictionary()
+
+
+def _derived_of(module):
+    d = _derived.get(module)
+    if d is None:
+        d = _derived[module] = {}
+    return d
 
 
 
@@ -164,6 +177,51 @@ class SynthesisInput(torch.nn.Module):
         t = self.affine(w)
         return t / t[:, :2].norm(dim=1, keepdim=True)
 
+    def sampling_grid(self, device):
+        """The [1,H,W,2] grid of sampling positions (reference :231-234): a function of the layer's geometry only, kept per device
+        in inference."""
+        theta = torch.eye(2, 3, device=device)        # scaled in place by scalar kernels: no host->device copy, so the
+        theta[0, 0].mul_(0.5 * self.size[0] / self.sampling_rate)   # forward can be captured into a HIP graph
+        theta[1, 1].mul_(0.5 * self.size[1] / self.sampling_rate)
+        return torch.nn.functional.affine_grid(theta.unsqueeze(0), [1, 1, self.size[1], self.size[0]], align_corners=False)
+
+    def fast_path_ok(self):
+        """GPU inference runs the features and their channel mix on HIP kernels; the mix kernel loads pixel pairs."""
+        return (int(self.size[0]) * int(self.size[1])) % 2 == 0
+
+    def _inference_constants(self, n, device):
+        """What GPU inference would otherwise recompute every call: the sampling grid, the scaled mixing matrix (as a 1x1
+        convolution weight; rebuilt when the parameter changes) and the all-ones style of that convolution."""
+        key = (str(device), self.weight.data_ptr(), self.weight._version)
+        store = _derived_of(self)
+        c = store.get('input')
+        if c is None or c['key'] != key:
+            with torch.no_grad():
+                c = dict(key=key, grid=self.sampling_grid(device)[0].contiguous(),
+                         mix=(self.weight.detach() / np.sqrt(self.channels)).unsqueeze(2).unsqueeze(3).contiguous(), ones={})
+            store['input'] = c
+        if n not in c['ones']:
+            c['ones'][n] = torch.ones([n, self.channels], device=device)
+        return c['grid'], c['mix'], c['ones'][n]
+
+    def mix_spec(self, n, device):
+        """The channel mix (reference :243-244) as this network's first entry of `modulated_conv.prepare_batch`."""
+        _, mix, ones = self._inference_constants(n, device)
+        return dict(w=mix, s=ones, demodulate=False, padding=0, input_gain=None, x_bound=1.001, n=n,
+                    h=int(self.size[1]), wd=int(self.size[0]), dtype=torch.float32)
+
+    def forward_inference(self, t, normalise, prepared):
+        """GPU inference (no autograd): transform algebra, features and channel mix as three launches (reference :204-244).
+        t [N,4]: the affine output (`normalise`) or `transform_params` (already normalised); `prepared`: the entry of `mix_spec`."""
+        n = int(t.shape[0])
+        grid, mix, ones = self._inference_constants(n, t.device)
+        freqs, phases, amps = fourier_features.input_transform(t.to(torch.float32), self.transform.to(torch.float32), self.freqs, self.phases,
+                                                               self.bandwidth, self.sampling_rate, normalise)
+        x = fourier_features.fourier_features(grid, freqs, phases, amps)
+        x = modulated_conv2d(x, mix, ones, demodulate=False, x_bound=1.001, prepared=prepared)
+        misc.assert_shape(x, [n, self.channels, int(self.size[1]), int(self.size[0])])
+        return x
+
     def forward(self, w, t=None):
         if t is None:
             t = self.transform_params(w)
@@ -181,10 +239,7 @@ class SynthesisInput(torch.nn.Module):
         # fade out frequencies that the transform pushed beyond the band limit
         amps = (1 - (freqs.norm(dim=2) - self.bandwidth) / (self.sampling_rate / 2 - self.bandwidth)).clamp(0, 1)
 
-        theta = torch.eye(2, 3, device=device)        # scaled in place by scalar kernels: no host->device copy, so the
-        theta[0, 0].mul_(0.5 * self.size[0] / self.sampling_rate)   # forward can be captured into a HIP graph
-        theta[1, 1].mul_(0.5 * self.size[1] / self.sampling_rate)
-        grid = torch.nn.functional.affine_grid(theta.unsqueeze(0), [1, 1, self.size[1], self.size[0]], align_corners=False)
+        grid = self.sampling_grid(device)
 
         mix = self.weight / np.sqrt(self.channels)
         if grid.is_cuda and not torch.is_grad_enabled() and (int(self.size[0]) * int(self.size[1])) % 2 == 0:
@@ -282,11 +337,15 @@ class SynthesisLayer(torch.nn.Module):
             self._bound_key, self._bound = key, float(self.conv_clamp) * max(l1, 1.0) * 1.01
         return self._bound
 
+    def style_gain(self):
+        """ToRGB styles carry the 1/sqrt(fan_in) weight gain (reference :350-352)."""
+        return 1 / np.sqrt(self.in_channels * (self.conv_kernel ** 2)) if self.is_torgb else 1.0
+
     def styles_from_w(self, w):
-        """Per-input-channel modulation for latent w (ToRGB styles carry the 1/sqrt(fan_in) weight gain)."""
+        """Per-input-channel modulation for latent w."""
         styles = self.affine(w)
         if self.is_torgb:
-            styles = styles * (1 / np.sqrt(self.in_channels * (self.conv_kernel ** 2)))
+            styles = styles * self.style_gain()
         return styles
 
     def compute_dtype(self, force_fp32, device_type):
@@ -424,27 +483,47 @@ class SynthesisNetwork(torch.nn.Module):
         With `all_s` (dict from W2S, possibly edited) the affine layers are bypassed: StyleSpace path."""
         self._propagate_bounds()
         layers = self.layers()
+        given = ws if all_s is None else all_s['input']
+        # Inference on the GPU: every layer's styles are known before the first convolution, so the weight / style preparation
+        # of all convolutions is issued as one batch (two launches instead of thirty small, latency-bound ones)
+        batched = (self.batch_prep and given.is_cuda and not torch.is_grad_enabled() and not layer_kwargs.get('update_emas', False)
+                   and all(k in ('noise_mode', 'force_fp32', 'update_emas') for k in layer_kwargs))
+        t_in = None
         if all_s is None:
             misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
             per_layer = ws.to(torch.float32).unbind(dim=1)
-            t_in = self.input.transform_params(per_layer[0])
             styles = None
+            if not (batched and self.input.fast_path_ok()):
+                t_in = self.input.transform_params(per_layer[0])
         else:
             t_in = all_s['input']
             styles = [all_s[name] for name in self.layer_names]
-        # Inference on the GPU: every layer's styles are known before the first convolution, so the weight / style preparation
-        # of all convolutions is issued as one batch (two launches instead of thirty small, latency-bound ones)
-        batched = (self.batch_prep and t_in.is_cuda and not torch.is_grad_enabled() and not layer_kwargs.get('update_emas', False)
-                   and all(k in ('noise_mode', 'force_fp32', 'update_emas') for k in layer_kwargs))
         prepared = [None] * len(layers)
+        x = None
         if batched:
+            n = int(given.shape[0])
+            fast_input = self.input.fast_path_ok()
+            normalise = False
             if styles is None:
-                styles = [layer.styles_from_w(w) for layer, w in zip(layers, per_layer[1:])]
+                # every affine layer (the input's and the 15 layers') in one launch instead of ~45 (affine_batch.py)
+                ws32 = ws.to(torch.float32)
+                outs = self._affine_pack()(ws32 if ws32.stride(2) == 1 else ws32.contiguous(),
+                                           [self.input.affine] + [layer.affine for layer in layers], range(len(layers) + 1),
+                                           [1.0] + [layer.style_gain() for layer in layers])
+                styles = outs[1:]
+                if fast_input:
+                    t_in, normalise = outs[0], True          # the normalisation happens inside the input-transform kernel
             force_fp32 = bool(layer_kwargs.get('force_fp32', False))
-            gains = torch.stack([layer.magnitude_ema for layer in layers]).rsqrt()       # one launch for all layers' input gains
-            prepared = _modconv.prepare_batch([layer.conv_spec(s, int(t_in.shape[0]), force_fp32, gains[j:j + 1])
-                                               for j, (layer, s) in enumerate(zip(layers, styles))])
-        x = self.input(None, t=t_in)
+            gains = self._input_gains(layers)
+            specs = [layer.conv_spec(s, n, force_fp32, gains[j:j + 1]) for j, (layer, s) in enumerate(zip(layers, styles))]
+            if fast_input:
+                plans = _modconv.prepare_batch([self.input.mix_spec(n, given.device)] + specs)
+                prepared = plans[1:]
+                x = self.input.forward_inference(t_in, normalise, plans[0])
+            else:
+                prepared = _modconv.prepare_batch(specs)
+        if x is None:
+            x = self.input(None, t=t_in)
         for j, layer in enumerate(layers):
             if styles is not None:
                 x = layer(x, None, styles=styles[j], prepared=prepared[j], **layer_kwargs)
@@ -454,6 +533,21 @@ class SynthesisNetwork(torch.nn.Module):
             x = x * self.output_scale
         misc.assert_shape(x, [None, self.img_channels, self.img_resolution, self.img_resolution])
         return x.to(torch.float32)
+
+    def _affine_pack(self):
+        store = _derived_of(self)
+        if 'affine' not in store:
+            store['affine'] = affine_batch.AffinePack()
+        return store['affine']
+
+    def _input_gains(self, layers):
+        """rsqrt(magnitude_ema) of every layer as one [L] tensor, rebuilt when a buffer changes (two launches otherwise)."""
+        key = tuple((layer.magnitude_ema.data_ptr(), layer.magnitude_ema._version) for layer in layers)
+        store = _derived_of(self)
+        c = store.get('gains')
+        if c is None or c[0] != key:
+            c = store['gains'] = (key, torch.stack([layer.magnitude_ema for layer in layers]).rsqrt())
+        return c[1]
 
     def W2S(self, ws):
         """Latents -> StyleSpace: {'input': t [N,4], layer_name: styles [N, in_channels]} (reference :503-525)."""

@@ -61,11 +61,21 @@ class FourierParams(ctypes.Structure):
                 ('N', c_i32), ('C', c_i32), ('H', c_i32), ('W', c_i32)]
 
 
+class InputTransformParams(ctypes.Structure):
+    _fields_ = [('t', c_vp), ('user', c_vp), ('freqs', c_vp), ('phases', c_vp), ('outFreqs', c_vp), ('outPhases', c_vp), ('outAmps', c_vp),
+                ('N', c_i32), ('C', c_i32), ('normalise', c_i32), ('userStrideN', c_i32), ('bandwidth', c_f32), ('samplingRate', c_f32)]
+
+
+class AffineBatchParams(ctypes.Structure):
+    _fields_ = [('ws', c_vp), ('wsStrideN', c_i64), ('wsStrideL', c_i64), ('weight', c_vp), ('bias', c_vp), ('scale', c_vp),
+                ('rowStart', c_vp), ('wsIndex', c_vp), ('out', c_vp), ('N', c_i32), ('wDim', c_i32), ('layers', c_i32), ('rows', c_i32)]
+
+
 class ModconvPrepParams(ctypes.Structure):
     _fields_ = [('w', c_vp), ('s', c_vp), ('wPacked', c_vp), ('wsq', c_vp), ('sIn', c_vp), ('dcoef', c_vp),
                 ('inputGain', c_vp), ('inputGainMode', c_i32),
                 ('N', c_i32), ('I', c_i32), ('O', c_i32), ('k', c_i32), ('demodulate', c_i32), ('precision', c_i32), ('xBound', c_f32),
-                ('xBoundDev', c_vp)]
+                ('xBoundDev', c_vp), ('reuseWeights', c_i32)]
 
 
 class WgradParams(ctypes.Structure):
@@ -97,6 +107,8 @@ EXPORTS = [
     ('sg3_modconv_packed_floats', ctypes.c_int64, [ctypes.c_int] * 4),
     ('sg3_modulated_conv2d', ctypes.c_int, [ctypes.POINTER(ModconvParams), c_vp]),
     ('sg3_fourier_features', ctypes.c_int, [ctypes.POINTER(FourierParams), c_vp]),
+    ('sg3_input_transform', ctypes.c_int, [ctypes.POINTER(InputTransformParams), c_vp]),
+    ('sg3_affine_batch', ctypes.c_int, [ctypes.POINTER(AffineBatchParams), c_vp]),
     ('sg3_modulated_conv2d_prep', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), c_vp]),
     ('sg3_modulated_conv2d_prep_batch', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), ctypes.c_int, c_vp]),
     ('sg3_conv2d', ctypes.c_int, [ctypes.POINTER(Conv2dParams), c_vp]),

@@ -27,3 +27,27 @@ def fourier_features(grid, freqs, phases, amps):
     with torch.cuda.device(grid.device):
         abi.check(lib.sg3_fourier_features(ctypes.byref(p), abi.stream_ptr(grid.device)), 'sg3_fourier_features')
     return out
+
+
+def input_transform(t, user, freqs, phases, bandwidth, sampling_rate, normalise):
+    """The transform algebra of `SynthesisInput.forward` (reference :204-230) in one launch.
+    t [N,4] (straight from the affine layer when `normalise`, else already divided by |t[:2]|), user [3,3] or [N,3,3],
+    freqs [C,2], phases [C]  ->  (freqs [N,C,2], phases [N,C], amplitudes [N,C]) for `fourier_features`."""
+    if not (t.is_cuda and t.dtype == user.dtype == freqs.dtype == phases.dtype == torch.float32):
+        raise RuntimeError('input_transform: float32 CUDA tensors expected')
+    n, c = int(t.shape[0]), int(freqs.shape[0])
+    if tuple(t.shape) != (n, 4) or tuple(freqs.shape) != (c, 2) or tuple(phases.shape) != (c,) or tuple(user.shape) not in ((3, 3), (n, 3, 3)):
+        raise RuntimeError(f'input_transform: shapes {tuple(t.shape)}, {tuple(user.shape)}, {tuple(freqs.shape)}, {tuple(phases.shape)}')
+    lib = abi.load()
+    t, user, freqs, phases = t.contiguous(), user.contiguous(), freqs.contiguous(), phases.contiguous()
+    out_f = torch.empty([n, c, 2], dtype=torch.float32, device=t.device)
+    out_p = torch.empty([n, c], dtype=torch.float32, device=t.device)
+    out_a = torch.empty([n, c], dtype=torch.float32, device=t.device)
+    p = abi.InputTransformParams()
+    p.t, p.user, p.freqs, p.phases = abi.ptr(t), abi.ptr(user), abi.ptr(freqs), abi.ptr(phases)
+    p.outFreqs, p.outPhases, p.outAmps = abi.ptr(out_f), abi.ptr(out_p), abi.ptr(out_a)
+    p.N, p.C, p.normalise, p.userStrideN = n, c, int(bool(normalise)), (9 if user.ndim == 3 else 0)
+    p.bandwidth, p.samplingRate = float(bandwidth), float(sampling_rate)
+    with torch.cuda.device(t.device):
+        abi.check(lib.sg3_input_transform(ctypes.byref(p), abi.stream_ptr(t.device)), 'sg3_input_transform')
+    return out_f, out_p, out_a

@@ -158,9 +158,11 @@ def test_config_r_full_size_against_reference_samples(cfg):
 
 @pytest.mark.gpu
 def test_batched_prep_matches_per_layer_prep():
-    """Inference batches the weight / style preparation of all convolutions into two launches (prepare_batch); with
-    the switch off every layer prepares for itself.  Same kernels, same numbers: the images are identical bit for bit.
-    A prepared entry used for another call shape is refused."""
+    """Inference batches the weight / style preparation of all convolutions into two launches (prepare_batch), evaluates all
+    affine layers in one (affine_batch) and the input's transform algebra in one (input_transform); with the switch off every
+    layer prepares for itself with torch ops.  Same convolution kernels on the same prepared operands: a convolution with a
+    batch-prepared entry equals the self-preparing call bit for bit, cached packed weights included; the images agree to
+    rounding (the affine dot products are summed in another order).  A prepared entry used for another call shape is refused."""
     import torch
     from synth_weights import synth_ws
     from torch_utils.ops import modulated_conv as mc
@@ -177,13 +179,87 @@ def test_batched_prep_matches_per_layer_prep():
             b16 = G.synthesis(ws, noise_mode='const')
         finally:
             del G.synthesis.batch_prep
-    assert torch.equal(a, b) and torch.equal(a16, b16) and torch.equal(a, a_s)
+    for x, y, tol in ((a, b, 5e-6), (a_s, b, 5e-6), (a16, b16, 2e-3)):
+        assert float((x - y).abs().max()) <= tol * max(1.0, float(y.abs().max()))
+    with torch.no_grad():
+        for j in (0, 3, len(G.synthesis.layers()) - 1):
+            layer = G.synthesis.layers()[j]
+            spec = layer.conv_spec(s[G.synthesis.layer_names[j]], 2, True)
+            x = torch.randn(2, layer.in_channels, int(layer.in_size[1]), int(layer.in_size[0]), device='cuda:0').clamp(-3, 3)
+            kw = dict(padding=spec['padding'], input_gain=spec['input_gain'], x_bound=3.0, demodulate=spec['demodulate'])
+            spec = dict(spec, x_bound=3.0)
+            own = mc.modulated_conv2d(x, layer.weight, spec['s'], **kw)
+            first = mc.modulated_conv2d(x, layer.weight, spec['s'], prepared=mc.prepare_batch([spec])[0], **kw)
+            again = mc.prepare_batch([spec])[0]                      # second time: the packed weights come from the cache
+            assert again.params.reuseWeights == 1
+            assert torch.equal(own, first) and torch.equal(own, mc.modulated_conv2d(x, layer.weight, spec['s'], prepared=again, **kw))
+        # a changed weight is packed again (optimiser steps, copy_, load_state_dict bump the version)
+        layer.weight.mul_(1.5)
+        changed = mc.prepare_batch([spec])[0]
+        assert changed.params.reuseWeights == 0
+        assert torch.equal(mc.modulated_conv2d(x, layer.weight, spec['s'], prepared=changed, **kw), mc.modulated_conv2d(x, layer.weight, spec['s'], **kw))
     layer = G.synthesis.layers()[0]
     spec = layer.conv_spec(s[G.synthesis.layer_names[0]], 2, True)
     pr = mc.prepare_batch([spec])[0]
     x = torch.randn(2, layer.in_channels, int(layer.in_size[1]) + 2, int(layer.in_size[0]), device='cuda:0')
     with pytest.raises(RuntimeError, match='prepared for'):
         mc.modulated_conv2d(x, layer.weight, spec['s'], padding=spec['padding'], input_gain=spec['input_gain'], x_bound=1e3, prepared=pr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cfg', ['Ttiny', 'Rtiny', 'T1024'])
+def test_affine_batch_and_input_transform_match_the_torch_ops(cfg):
+    """All affine layers in one launch == each layer's own addmm; the input's transform algebra in one launch == the torch op
+    chain of SynthesisInput.forward ([3,3] and per-sample [N,3,3] user transforms, t normalised inside or before).  Changing a
+    parameter in place is seen (the packs are keyed on parameter versions)."""
+    import torch
+    from synth_weights import make_user_transform, synth_ws
+    from torch_utils.ops import fourier_features as ff
+    G = build_product_generator(cfg, device='cuda:0')
+    syn = G.synthesis
+    layers = syn.layers()
+    n = 3
+    ws = torch.from_numpy(synth_ws(n, G.num_ws, G.w_dim, 8)).cuda()
+    fcs = [syn.input.affine] + [layer.affine for layer in layers]
+    post = [1.0] + [layer.style_gain() for layer in layers]
+
+    def check():
+        outs = syn._affine_pack()(ws, fcs, range(len(fcs)), post)
+        assert len(outs) == len(fcs) and all(o.is_contiguous() for o in outs)
+        refs = [syn.input.affine(ws[:, 0])] + [layer.styles_from_w(ws[:, j + 1]) for j, layer in enumerate(layers)]
+        for o, r in zip(outs, refs):
+            assert o.shape == r.shape and float((o - r).abs().max()) <= 2e-6 * max(1.0, float(r.abs().max()))
+        return outs
+    with torch.no_grad():
+        outs = check()
+        layers[1].affine.weight.mul_(0.5); layers[2].affine.bias.add_(0.25)
+        outs2 = check()
+        assert not torch.equal(outs[2], outs2[2]) and not torch.equal(outs[3], outs2[3])
+        # non-contiguous latents (a slice of a wider tensor) through the strides
+        wide = torch.randn(n, G.num_ws + 2, G.w_dim, device='cuda:0')
+        got = syn._affine_pack()(wide[:, 1:-1], fcs, range(len(fcs)), post)
+        assert float((got[4] - layers[3].styles_from_w(wide[:, 5])).abs().max()) <= 2e-6 * float(got[4].abs().max())
+
+        inp = syn.input
+        t_raw = outs2[0]
+        users = [torch.eye(3, device='cuda:0'), torch.from_numpy(make_user_transform((0.1, -0.05), 15.0)).float().cuda(),
+                 torch.from_numpy(np.stack([make_user_transform((0.1 * i, -0.05), 15.0 * i) for i in range(n)])).float().cuda()]
+        for user in users:
+            t = t_raw / t_raw[:, :2].norm(dim=1, keepdim=True)
+            rot = torch.eye(3, device='cuda:0').repeat(n, 1, 1)
+            rot[:, 0, 0], rot[:, 0, 1], rot[:, 1, 0], rot[:, 1, 1] = t[:, 0], -t[:, 1], t[:, 1], t[:, 0]
+            trans = torch.eye(3, device='cuda:0').repeat(n, 1, 1)
+            trans[:, 0, 2], trans[:, 1, 2] = -t[:, 2], -t[:, 3]
+            m = rot @ trans @ user
+            f = inp.freqs.unsqueeze(0)
+            ph = inp.phases.unsqueeze(0) + (f @ m[:, :2, 2:]).squeeze(2)
+            f = f @ m[:, :2, :2]
+            am = (1 - (f.norm(dim=2) - inp.bandwidth) / (inp.sampling_rate / 2 - inp.bandwidth)).clamp(0, 1)
+            for tt, normalise in ((t_raw, True), (t, False)):
+                gf, gp, ga = ff.input_transform(tt, user, inp.freqs, inp.phases, inp.bandwidth, inp.sampling_rate, normalise)
+                scale = max(1.0, float(f.abs().max()))
+                assert float((gf - f).abs().max()) <= 2e-6 * scale and float((gp - ph).abs().max()) <= 2e-6 * scale
+                assert float((ga - am).abs().max()) <= 2e-6
 
 
 def test_torgb_epilogue_fused_and_refused():
