@@ -377,6 +377,9 @@ modconv_f16x3_kernel(ConvParams p) {
         for (int ky = 0; ky < 3; ky++) { const int b = pr - ky; if (b >= 0 && b < TN) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ky], f.h, acc[0][b], 0, 0, 0); }
     };
 
+    // A wave whose 32 channels lie beyond O (O = 323: the second M block of the sixth 64-channel tile) or whose rows lie beyond the
+    // image stages and synchronises with its workgroup but issues no MFMAs: the matrix pipe and its power go to the CU's other waves
+    const bool active = o0 + wm * 32 < p.O && y0 + wn * TN < p.outH;          // wave-uniform
     // PACK: the last chunk holds at most 4 channels and is peeled off the loop (below)
     const int nMain = PACK ? p.nch - 1 : p.nch;
     fetch(0);
@@ -385,6 +388,7 @@ modconv_f16x3_kernel(ConvParams p) {
         stage(ch);
         __syncthreads();
         if (ch + 1 < p.nch) fetch(ch + 1);
+        if (!active) continue;
         // the wave that is in its MFMA loop gets issue priority over the other workgroup's wave on the same SIMD (which is
         // staging or waiting): L6 2331 -> 2236 us, L8 2230 -> 2116 us; no effect on the thin layers
         __builtin_amdgcn_s_setprio(1);
@@ -426,6 +430,7 @@ modconv_f16x3_kernel(ConvParams p) {
         stage(p.nch - 1);
         __syncthreads();
         typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+        if (active) {
         auto two = [](const _Float16* a, const _Float16* b) {
             return __builtin_shufflevector(*reinterpret_cast<const v4h*>(a), *reinterpret_cast<const v4h*>(b), 0, 1, 2, 3, 4, 5, 6, 7);
         };
@@ -447,6 +452,7 @@ modconv_f16x3_kernel(ConvParams p) {
             __builtin_amdgcn_sched_barrier(0);
             mfma_row(f, ah, al, pr);
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
     }
 
@@ -646,6 +652,7 @@ modconv_flat_kernel(ConvParams p) {
             if (SPLIT) al = *reinterpret_cast<const v8h*>(aBase + tap * 32 + 16);
 #pragma unroll
             for (int b = 0; b < TN; b++) {
+                if (f0 + (wn * TN + b) * 32 >= P) continue;                  // wave-uniform: a run beyond the plane issues no MFMAs
                 const _Float16* src = bBase + pb[b] + toff;
                 const v8h bh = *reinterpret_cast<const v8h*>(src);
                 if (SPLIT) {
@@ -823,9 +830,13 @@ modconv1_f16x3_kernel(ConvParams p) {
             if (SPLIT) f.bl[b] = *reinterpret_cast<const v8h*>(src + BPLANE);
         }
     };
+    // 16-row blocks of this wave's M range that hold real output channels (wave-uniform): blocks of pure channel padding
+    // (O = 645 in 256-row tiles: 112 of 768 rows; O = 406: 96 of 512) issue no MFMAs
+    const int act16 = min(max((p.O - o0 - wm * TM * 32 + 15) / 16, 0), 2 * TM);
     auto mfma_step = [&](const Frags& f) {
 #pragma unroll
-        for (int a = 0; a < TM; a++)
+        for (int a = 0; a < TM; a++) {
+            if (2 * a >= act16) continue;
 #pragma unroll
             for (int b = 0; b < TN; b++) {
                 if (SPLIT) {
@@ -834,6 +845,7 @@ modconv1_f16x3_kernel(ConvParams p) {
                 }
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[a], f.bh[b], acc[a][b], 0, 0, 0);
             }
+        }
     };
 
     // M16: one stage (32 channels) = one K step.  Fragments of one 16-row block of A at a time (its 2 TN x 2 B fragments are
@@ -854,6 +866,7 @@ modconv1_f16x3_kernel(ConvParams p) {
         for (int a = 0; a < TM; a++)
 #pragma unroll
             for (int rb_ = 0; rb_ < 2; rb_++) {
+                if (2 * a + rb_ >= act16) continue;
                 const _Float16* src = sA + ((wm * TM + a) * 32 + rb_ * 16 + l16) * AS + (lg >> 1) * 32 + (lg & 1) * 8;
                 const v8h ah = *reinterpret_cast<const v8h*>(src);
                 v8h al;
