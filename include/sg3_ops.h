@@ -448,6 +448,25 @@ SG3_API int sg3_conv2d(const sg3_conv2d_params* p, void* stream);
 /* w [O,I,k,k] (* outScale[o] when given: a folded BatchNorm) -> packed layout */
 SG3_API int sg3_conv2d_pack(const float* w, const float* outScale, float* wPacked, int O, int I, int k, int precision, void* stream);
 
+/* ------------------------------------------------------------------------
+ * se_residual -- the tail of an IR-SE residual unit (models/setgan/encoder/encoders/helpers.py:78-96 SEModule and
+ *   :127-141 bottleneck_IR_SE.forward):  out = shortcut + res * sigmoid(fc2 @ relu(fc1 @ mean_hw(res))).
+ *   Two launches (plane means; gates + apply) instead of the seven of the torch op chain.  float32, res / out dense NCHW;
+ *   the shortcut is addressed through element strides (the stride-2 units read a subsampled view of their input).
+ * ---------------------------------------------------------------------- */
+typedef struct sg3_se_params {
+    const float*   res;        /* [N,C,H,W] dense: the residual branch (after its last BatchNorm) */
+    const float*   shortcut;   /* [N,C,H,W] through scStride */
+    int64_t        scStride[4];/* elements, n,c,h,w */
+    const float*   fc1;        /* [R,C] */
+    const float*   fc2;        /* [C,R] */
+    float*         mean;       /* [N,C] scratch (holds mean_hw(res) afterwards) */
+    float*         out;        /* [N,C,H,W] dense; may alias res */
+    int32_t        N, C, H, W, R;
+} sg3_se_params;
+
+SG3_API int sg3_se_residual(const sg3_se_params* p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

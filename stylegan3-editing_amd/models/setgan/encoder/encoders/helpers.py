@@ -6,6 +6,7 @@ SEModule :57-73, bottleneck_IR :76-95, bottleneck_IR_SE :98-120).
 calls `forward_hip()`, which runs the two 3x3 convolutions on the matrix cores with their element-wise neighbours
 fused (torch_utils/ops/plain_conv.py): BN1 as an input affine of conv1, PReLU as its epilogue, BN2 folded into conv2.
 """
+import os
 from collections import namedtuple
 
 import torch
@@ -38,6 +39,10 @@ def get_blocks(num_layers):
     units = _STAGES[num_layers]
     widths = [(64, 64), (64, 128), (128, 256), (256, 512)]
     return [get_block(in_channel=i, depth=d, num_units=u) for (i, d), u in zip(widths, units)]
+
+
+# GPU inference runs the squeeze-and-excitation tail on two HIP kernels unless SG3_SE_TORCH=1 (A/B timing)
+_SE_KERNELS = os.environ.get('SG3_SE_TORCH', '0') != '1'
 
 
 class SEModule(Module):
@@ -106,7 +111,11 @@ class _ResidualUnit(Module):
         else:
             shortcut = x if self.stride == 1 else x[:, :, ::self.stride, ::self.stride]
         if self.use_se:
-            return torch.addcmul(shortcut, res, self.res_layer[5].gate(res))
+            se = self.res_layer[5]
+            if res.is_cuda and res.dtype == torch.float32 and not torch.is_grad_enabled() and _SE_KERNELS:
+                from torch_utils.ops import se_ops
+                return se_ops.se_residual(res.contiguous(), shortcut, se.fc1.weight, se.fc2.weight)      # two launches
+            return torch.addcmul(shortcut, res, se.gate(res))
         return res + shortcut
 
 

@@ -66,6 +66,11 @@ class InputTransformParams(ctypes.Structure):
                 ('N', c_i32), ('C', c_i32), ('normalise', c_i32), ('userStrideN', c_i32), ('bandwidth', c_f32), ('samplingRate', c_f32)]
 
 
+class SeParams(ctypes.Structure):
+    _fields_ = [('res', c_vp), ('shortcut', c_vp), ('scStride', c_i64 * 4), ('fc1', c_vp), ('fc2', c_vp), ('mean', c_vp), ('out', c_vp),
+                ('N', c_i32), ('C', c_i32), ('H', c_i32), ('W', c_i32), ('R', c_i32)]
+
+
 class AffineBatchParams(ctypes.Structure):
     _fields_ = [('ws', c_vp), ('wsStrideN', c_i64), ('wsStrideL', c_i64), ('weight', c_vp), ('bias', c_vp), ('scale', c_vp),
                 ('rowStart', c_vp), ('wsIndex', c_vp), ('out', c_vp), ('N', c_i32), ('wDim', c_i32), ('layers', c_i32), ('rows', c_i32)]
@@ -109,6 +114,7 @@ EXPORTS = [
     ('sg3_fourier_features', ctypes.c_int, [ctypes.POINTER(FourierParams), c_vp]),
     ('sg3_input_transform', ctypes.c_int, [ctypes.POINTER(InputTransformParams), c_vp]),
     ('sg3_affine_batch', ctypes.c_int, [ctypes.POINTER(AffineBatchParams), c_vp]),
+    ('sg3_se_residual', ctypes.c_int, [ctypes.POINTER(SeParams), c_vp]),
     ('sg3_modulated_conv2d_prep', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), c_vp]),
     ('sg3_modulated_conv2d_prep_batch', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), ctypes.c_int, c_vp]),
     ('sg3_conv2d', ctypes.c_int, [ctypes.POINTER(Conv2dParams), c_vp]),

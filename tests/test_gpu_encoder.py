@@ -162,3 +162,25 @@ def test_resnet34_encoder_hip_path():
         b = prog(torch.from_numpy(x).to(DEV))
     assert maxabs(b[:, 0].cpu().numpy(), codes[:, 0].cpu().numpy()) <= 1e-5 * scale
     assert maxabs(b[:, 3].cpu().numpy(), (codes[:, 0] + codes[:, 3]).cpu().numpy()) <= 1e-5 * scale
+
+
+@pytest.mark.parametrize('n,c,h,w,strided', [(2, 64, 128, 128, False), (3, 128, 20, 24, True), (1, 512, 16, 16, False), (2, 256, 7, 9, True),
+                                             (2, 70, 5, 6, False)])
+def test_se_residual_kernels(n, c, h, w, strided):
+    """shortcut + res * sigmoid(fc2 @ relu(fc1 @ mean_hw(res))) in two launches == the torch op chain of SEModule +
+    bottleneck_IR_SE (dense and stride-2 subsampled shortcuts, plane sizes that are not multiples of 4, C not a multiple of 8)."""
+    from torch_utils.ops import se_ops
+    r = max(1, c // 16)
+    g = np.random.RandomState(3)
+    T = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(DEV)  # noqa: E731
+    res = T(g.randn(n, c, h, w))
+    big = T(g.randn(n, c, 2 * h, 2 * w))
+    shortcut = big[:, :, ::2, ::2] if strided else T(g.randn(n, c, h, w))
+    fc1 = T(g.randn(r, c, 1, 1) / np.sqrt(c)); fc2 = T(g.randn(c, r, 1, 1) / np.sqrt(r))
+    m = res.mean(dim=(2, 3))
+    gate = torch.sigmoid(torch.relu(m @ fc1.flatten(1).t()) @ fc2.flatten(1).t())
+    ref = shortcut + res * gate[:, :, None, None]
+    buf = res.clone()
+    out = se_ops.se_residual(buf, shortcut, fc1, fc2)
+    assert out.data_ptr() == buf.data_ptr()
+    assert float((out - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
