@@ -449,8 +449,8 @@ SG3_API int sg3_conv2d(const sg3_conv2d_params* p, void* stream);
 SG3_API int sg3_conv2d_pack(const float* w, const float* outScale, float* wPacked, int O, int I, int k, int precision, void* stream);
 
 /* ------------------------------------------------------------------------
- * se_residual -- the tail of an IR-SE residual unit (models/setgan/encoder/encoders/helpers.py:78-96 SEModule and
- *   :127-141 bottleneck_IR_SE.forward):  out = shortcut + res * sigmoid(fc2 @ relu(fc1 @ mean_hw(res))).
+ * se_residual -- the tail of an IR-SE residual unit (models/setgan/encoder/encoders/helpers.py:57-73 SEModule and
+ *   :117-120 bottleneck_IR_SE.forward):  out = shortcut + res * sigmoid(fc2 @ relu(fc1 @ mean_hw(res))).
  *   Two launches (plane means; gates + apply) instead of the seven of the torch op chain.  float32, res / out dense NCHW;
  *   the shortcut is addressed through element strides (the stride-2 units read a subsampled view of their input).
  * ---------------------------------------------------------------------- */

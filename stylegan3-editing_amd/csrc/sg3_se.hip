@@ -1,6 +1,6 @@
 // sg3_se.hip -- the squeeze-and-excitation tail of an IR-SE residual unit in two launches.
 //
-// Reference (models/setgan/encoder/encoders/helpers.py:78-96 SEModule, :127-141 bottleneck_IR_SE.forward):
+// Reference (models/setgan/encoder/encoders/helpers.py:57-73 SEModule, :117-120 bottleneck_IR_SE.forward):
 //     g   = sigmoid(fc2(relu(fc1(mean_hw(res)))))        two bias-free 1x1 convolutions on a [N,C,1,1] tensor
 //     out = shortcut + res * g
 // As torch ops that is a mean, two tiny GEMMs, relu, sigmoid and an addcmul per unit -- seven launches of ~5 us each, 24 units

@@ -1,7 +1,7 @@
 """Squeeze-and-excitation tail of the IR-SE residual units on libsg3hip (csrc/sg3_se.hip: sg3_se_residual).
 
 Replaces, for GPU inference, `shortcut + res * sigmoid(fc2(relu(fc1(mean_hw(res)))))` of the reference's `SEModule` +
-`bottleneck_IR_SE.forward` (models/setgan/encoder/encoders/helpers.py:78-96, :127-141): seven torch launches -> two."""
+`bottleneck_IR_SE.forward` (models/setgan/encoder/encoders/helpers.py:57-73, :117-120): seven torch launches -> two."""
 import ctypes
 
 import torch
