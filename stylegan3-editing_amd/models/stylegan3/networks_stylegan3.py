@@ -35,6 +35,26 @@ from torch_utils.ops import modulated_conv as _modconv
 _derived = weakref.WeakKeyDictionary()
 
 
+def derived_tensors(root):
+    """Every tensor the tables above hold for `root` and its submodules (what a captured graph of `root` may read)."""
+    found = []
+
+    def walk(v):
+        if isinstance(v, torch.Tensor):
+            found.append(v)
+        elif isinstance(v, dict):
+            for x in v.values():
+                walk(x)
+        elif isinstance(v, (list, tuple)):
+            for x in v:
+                walk(x)
+        elif isinstance(v, affine_batch.AffinePack):
+            walk([getattr(v, n, None) for n in ('weight', 'bias', 'scale', 'row_start', 'ws_index')])
+    for m in root.modules():
+        walk(_derived.get(m))
+    return found
+
+
 def _derived_of(module):
     d = _derived.get(module)
     if d is None:

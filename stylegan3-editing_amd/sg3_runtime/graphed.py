@@ -18,6 +18,16 @@ What a captured graph bakes in, and how a replay stays valid:
 import torch
 
 
+
+def _cached_inference_tensors(synthesis):
+    """Inference caches derived from the parameters (packed convolution weights, the affine pack, the input's grid / mixing
+    matrix, the layers' input gains) were filled during the warm-up and are read by the captured kernels: the graph keeps them
+    alive, whatever happens to the caches afterwards."""
+    from models.stylegan3 import networks_stylegan3
+    from torch_utils.ops import modulated_conv
+    return modulated_conv.cached_weight_tensors() + networks_stylegan3.derived_tensors(synthesis)
+
+
 class GraphedSynthesis:
     def __init__(self, generator, batch, all_s_template=None, warmup=2, **synthesis_kwargs):
         """generator: a Generator (or anything with .synthesis / .num_ws / .w_dim) on a CUDA device."""
@@ -50,6 +60,7 @@ class GraphedSynthesis:
         with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.static_out = self._eager()
         self._fingerprint = self._weights_fingerprint()
+        self._pinned = _cached_inference_tensors(self.G.synthesis)
 
     def _install_transform(self, t):
         """Copy `t` ([3,3] or [batch,3,3]) into the graph's transform buffer and make that buffer the module's transform."""
@@ -118,6 +129,7 @@ class GraphedReStyleStep:
         with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.image, self.latent, self.pooled = self._eager()
         self._fingerprint = self._weights_fingerprint()
+        self._pinned = _cached_inference_tensors(self.net.decoder.synthesis)
 
     def _weights_fingerprint(self):
         G = self.net.decoder

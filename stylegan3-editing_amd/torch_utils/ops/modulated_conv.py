@@ -84,6 +84,12 @@ def clear_weight_cache():
     _packed_weights.clear()
 
 
+def cached_weight_tensors():
+    """The tensors the cache holds right now: a captured graph reads them, so its owner keeps these references (a later
+    `clear_weight_cache()` or re-pack must not hand their memory back to the allocator under the graph)."""
+    return [t for ent in _packed_weights.values() for t in ent[2:]]
+
+
 def _cached_packed_weights(w, key):
     ent = _packed_weights.get(id(w))
     if ent is not None and ent[0]() is w and ent[1] == key:

@@ -327,3 +327,28 @@ def test_graph_replay_follows_transform_rebinding_and_refuses_stale_weights():
         G.synthesis.L3_36_12.bias.add_(0.5)                    # tuning step
     with pytest.raises(RuntimeError, match='changed since capture'):
         graphed(ws)
+
+
+def test_graph_replay_survives_cache_turnover():
+    """Inference caches (packed convolution weights, affine pack, input constants, gains) are filled during the warm-up and read by
+    the captured kernels; clearing or rebuilding them afterwards must not pull memory from under the graph."""
+    import gc
+    from sg3_runtime import GraphedSynthesis
+    from models.stylegan3 import networks_stylegan3 as ns
+    from torch_utils.ops import modulated_conv as mc
+    G = build_product_generator('Ttiny', device=DEV)
+    ws = T(synth_ws(2, G.num_ws, G.w_dim, seed=1))
+    graphed = GraphedSynthesis(G, 2)
+    with torch.no_grad():
+        want = G.synthesis(ws, noise_mode='const', force_fp32=True).clone()
+    assert maxabs(graphed(ws).cpu().numpy(), want.cpu().numpy()) <= 1e-6
+    mc.clear_weight_cache()
+    for m in G.synthesis.modules():
+        ns._derived.pop(m, None)
+    gc.collect()
+    junk = [torch.randn(1 << 16, device=DEV) for _ in range(256)]          # recycle whatever the caches would have freed
+    other = build_product_generator('Rtiny', device=DEV)                    # and fill the caches with another network's tensors
+    with torch.no_grad():
+        other.synthesis(T(synth_ws(3, other.num_ws, other.w_dim, seed=2)), noise_mode='const', force_fp32=True)
+    del junk
+    assert maxabs(graphed(ws).cpu().numpy(), want.cpu().numpy()) <= 1e-6
