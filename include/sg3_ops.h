@@ -369,7 +369,7 @@ typedef struct sg3_modconv_params {
     int32_t        precision;  /* must match the prep call that produced wPacked */
     /* Optional epilogue of the ToRGB form only (k = 1, pad = 0, O <= 4, SG3_CONV_FP32): the bias + clamp that
      * SynthesisLayer.forward applies next through filtered_lrelu with up = down = 1, gain = 1, slope = 1
-     * (networks_stylegan3.py:352-356), optionally followed by a scale such as SynthesisNetwork's output scale (:493-494):
+     * (networks_stylegan3.py:352-356), optionally followed by a scale such as SynthesisNetwork's output scale (:488-489):
      * out = clamp(conv + bias[o], +-epilogueClamp) * epilogueScale -- the same values without further passes over the
      * image.  epilogueBias NULL = no epilogue; epilogueClamp < 0 = no clamp; epilogueScale 0 = 1. */
     const float*   epilogueBias;

@@ -384,7 +384,7 @@ class SynthesisLayer(torch.nn.Module):
         return (self.is_torgb and self.up_factor == 1 and self.down_factor == 1 and self.up_filter is None and self.down_filter is None
                 and not any(self.padding) and _modconv.torgb_epilogue_ok(self.weight, self.conv_kernel - 1, dtype))
 
-    def forward(self, x, w, styles=None, noise_mode='random', force_fp32=False, update_emas=False, prepared=None):
+    def forward(self, x, w, styles=None, noise_mode='random', force_fp32=False, update_emas=False, prepared=None, out_scale=1.0):
         assert noise_mode in ['random', 'const', 'none']  # kept for API compatibility; SG3 has no noise inputs
         in_w, in_h = (int(v) for v in self.in_size)
         out_w, out_h = (int(v) for v in self.out_size)
@@ -400,7 +400,9 @@ class SynthesisLayer(torch.nn.Module):
         dtype = self.compute_dtype(force_fp32, x.device.type)
         epilogue = None
         if prepared is not None and self.fuses_output(dtype):
-            epilogue = (self.bias, self.conv_clamp, 1.0)       # clamp(conv + bias) inside the convolution
+            epilogue = (self.bias, self.conv_clamp, float(out_scale))       # clamp(conv + bias) [* out_scale] inside the convolution
+        elif out_scale != 1.0:
+            raise RuntimeError('SynthesisLayer: out_scale rides in the fused ToRGB output stage only')
         x = modulated_conv2d(x=x.to(dtype), w=self.weight, s=styles, padding=self.conv_kernel - 1,
                              demodulate=(not self.is_torgb), input_gain=input_gain, x_bound=getattr(self, 'input_bound', None),
                              prepared=prepared, epilogue=epilogue,
@@ -544,12 +546,19 @@ class SynthesisNetwork(torch.nn.Module):
                 prepared = _modconv.prepare_batch(specs)
         if x is None:
             x = self.input(None, t=t_in)
+        scaled = False
         for j, layer in enumerate(layers):
             if styles is not None:
-                x = layer(x, None, styles=styles[j], prepared=prepared[j], **layer_kwargs)
+                # the network's output scale (reference :488-489) rides in the last layer's fused output stage
+                # (not when somebody watches the layer's own output through a forward hook)
+                hooked = bool(layer._forward_hooks) or bool(torch.nn.modules.module._global_forward_hooks)
+                last = (j + 1 == len(layers) and prepared[j] is not None and self.output_scale != 1 and not hooked
+                        and layer.fuses_output(layer.compute_dtype(bool(layer_kwargs.get('force_fp32', False)), 'cuda')))
+                x = layer(x, None, styles=styles[j], prepared=prepared[j], **(dict(layer_kwargs, out_scale=self.output_scale) if last else layer_kwargs))
+                scaled = last
             else:
                 x = layer(x, per_layer[j + 1], **layer_kwargs)
-        if self.output_scale != 1:
+        if self.output_scale != 1 and not scaled:
             x = x * self.output_scale
         misc.assert_shape(x, [None, self.img_channels, self.img_resolution, self.img_resolution])
         return x.to(torch.float32)
