@@ -449,6 +449,29 @@ SG3_API int sg3_conv2d(const sg3_conv2d_params* p, void* stream);
 SG3_API int sg3_conv2d_pack(const float* w, const float* outScale, float* wPacked, int O, int I, int k, int precision, void* stream);
 
 /* ------------------------------------------------------------------------
+ * modulation_backward -- dL/dw and dL/ds of modulated_conv2d's per-sample effective weights, given G = dL/dw_eff
+ *   (the output of sg3_conv2d_wgrad).  The reference gets them from autograd through its weight algebra
+ *   (models/stylegan3/networks_stylegan3.py:39-56: pre-normalisation of w and s, modulation, demodulation, input gain);
+ *   this is the same chain in closed form, four launches instead of ~70 (see csrc/sg3_modgrad.hip).  float32, dense tensors.
+ *   G is overwritten (it holds dL/dm afterwards).  The input gain is a constant here (a buffer in the reference).
+ * ---------------------------------------------------------------------- */
+typedef struct sg3_modgrad_params {
+    float*         G;          /* [N,O,I,T] dL/dw_eff; scratch on return */
+    const float*   w;          /* [O,I,T] raw weights */
+    const float*   s;          /* [N,I] raw styles */
+    const float*   inputGain;  /* as in sg3_modconv_prep_params, or NULL */
+    int32_t        inputGainMode;
+    float*         dW;         /* [O,I,T] */
+    float*         dS;         /* [N,I] */
+    float*         a;          /* [O] scratch */
+    float*         dSn;        /* [N,I] scratch */
+    int32_t        N, O, I, T; /* T = k * k taps */
+    int32_t        demodulate;
+} sg3_modgrad_params;
+
+SG3_API int sg3_modulation_backward(const sg3_modgrad_params* p, void* stream);
+
+/* ------------------------------------------------------------------------
  * se_residual -- the tail of an IR-SE residual unit (models/setgan/encoder/encoders/helpers.py:57-73 SEModule and
  *   :117-120 bottleneck_IR_SE.forward):  out = shortcut + res * sigmoid(fc2 @ relu(fc1 @ mean_hw(res))).
  *   Two launches (plane means; gates + apply) instead of the seven of the torch op chain.  float32, res / out dense NCHW;

@@ -66,6 +66,11 @@ class InputTransformParams(ctypes.Structure):
                 ('N', c_i32), ('C', c_i32), ('normalise', c_i32), ('userStrideN', c_i32), ('bandwidth', c_f32), ('samplingRate', c_f32)]
 
 
+class ModgradParams(ctypes.Structure):
+    _fields_ = [('G', c_vp), ('w', c_vp), ('s', c_vp), ('inputGain', c_vp), ('inputGainMode', c_i32), ('dW', c_vp), ('dS', c_vp),
+                ('a', c_vp), ('dSn', c_vp), ('N', c_i32), ('O', c_i32), ('I', c_i32), ('T', c_i32), ('demodulate', c_i32)]
+
+
 class SeParams(ctypes.Structure):
     _fields_ = [('res', c_vp), ('shortcut', c_vp), ('scStride', c_i64 * 4), ('fc1', c_vp), ('fc2', c_vp), ('mean', c_vp), ('out', c_vp),
                 ('N', c_i32), ('C', c_i32), ('H', c_i32), ('W', c_i32), ('R', c_i32)]
@@ -115,6 +120,7 @@ EXPORTS = [
     ('sg3_input_transform', ctypes.c_int, [ctypes.POINTER(InputTransformParams), c_vp]),
     ('sg3_affine_batch', ctypes.c_int, [ctypes.POINTER(AffineBatchParams), c_vp]),
     ('sg3_se_residual', ctypes.c_int, [ctypes.POINTER(SeParams), c_vp]),
+    ('sg3_modulation_backward', ctypes.c_int, [ctypes.POINTER(ModgradParams), c_vp]),
     ('sg3_modulated_conv2d_prep', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), c_vp]),
     ('sg3_modulated_conv2d_prep_batch', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), ctypes.c_int, c_vp]),
     ('sg3_conv2d', ctypes.c_int, [ctypes.POINTER(Conv2dParams), c_vp]),

@@ -267,6 +267,41 @@ def _weight_gradient(x, dy, k, padding, x_amax=None, dy_amax=None):
     return partial.sum(dim=0).permute(0, 2, 3, 1).reshape(n, co, ci, k, k)
 
 
+# First-order gradients of w and s go through the closed-form kernels of csrc/sg3_modgrad.hip unless SG3_MODGRAD_AUTOGRAD=1
+# (then, as for higher-order gradients, autograd differentiates the reference's weight algebra op by op: ~70 launches per layer)
+_MODGRAD_KERNELS = os.environ.get('SG3_MODGRAD_AUTOGRAD', '0') != '1'
+
+
+def _modulation_grads(dw_eff, w, s, input_gain, demodulate):
+    """dL/dw [O,I,k,k] and dL/ds [N,I] from dL/dw_eff [N,O,I,k,k] (sg3_modulation_backward; `dw_eff` is consumed).
+    `input_gain` is a constant here ([] | [I] | [N,I] or None)."""
+    lib = abi.load()
+    n, co, ci, k, _ = (int(v) for v in dw_eff.shape)
+    dev = dw_eff.device
+    g_eff = dw_eff.to(torch.float32).contiguous()
+    w32 = w.detach().to(torch.float32).contiguous()
+    s32 = s.detach().to(torch.float32).contiguous()
+    gmode, gptr = 0, None
+    if input_gain is not None:
+        g = input_gain.detach().to(device=dev, dtype=torch.float32)
+        if g.numel() == 1:
+            gmode, gptr = 1, g.reshape(1)
+        elif g.ndim <= 1 or (g.ndim == 2 and g.shape[0] == 1):
+            gmode, gptr = 2, g.reshape(-1).contiguous()
+        else:
+            gmode, gptr = 3, g.expand(n, ci).contiguous()
+    dw = torch.empty([co, ci, k, k], dtype=torch.float32, device=dev)
+    ds = torch.empty([n, ci], dtype=torch.float32, device=dev)
+    scratch = torch.empty([co + n * ci], dtype=torch.float32, device=dev)
+    p = abi.ModgradParams()
+    p.G, p.w, p.s, p.inputGain, p.inputGainMode = abi.ptr(g_eff), abi.ptr(w32), abi.ptr(s32), abi.ptr(gptr), gmode
+    p.dW, p.dS, p.a, p.dSn = abi.ptr(dw), abi.ptr(ds), abi.ptr(scratch), abi.ptr(scratch[co:])
+    p.N, p.O, p.I, p.T, p.demodulate = n, co, ci, k * k, int(bool(demodulate))
+    with torch.cuda.device(dev):
+        abi.check(lib.sg3_modulation_backward(ctypes.byref(p), abi.stream_ptr(dev)), 'sg3_modulation_backward')
+    return dw, ds
+
+
 class _ModulatedConv2dHip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, s, input_gain, demodulate, padding, x_bound, prepared=None, epilogue=None, align_rows=False):  # pylint: disable=arguments-differ
@@ -303,8 +338,19 @@ class _ModulatedConv2dHip(torch.autograd.Function):
         co, ci, k, _ = (int(v) for v in w.shape)
         if need[0]:
             out[0] = _data_gradient(dy, w, s_in, dcoef if dcoef.numel() else None, demodulate, padding, dy_amax=dy_amax)
-        if need[1] or need[2] or (has_gain and need[3]):
-            # gradient of the per-sample effective weights (weight-gradient kernel), then the chain rule
+        if (need[1] or need[2]) and not (has_gain and need[3]) and _MODGRAD_KERNELS:
+            # gradient of the per-sample effective weights (weight-gradient kernel), then the chain rule to w and s in closed form
+            x_amax = None
+            if ctx.x_bound is not None and ctx.x_bound > 0:
+                x_amax = torch.full([1], float(ctx.x_bound), dtype=torch.float32, device=x.device)     # the layer's own bound: no pass over x
+            dw_eff = _weight_gradient(x, dy, k, padding, x_amax=x_amax, dy_amax=dy_amax)
+            dw, ds = _modulation_grads(dw_eff, w, s, g if has_gain else None, demodulate)
+            if need[1]:
+                out[1] = dw.to(w.dtype)
+            if need[2]:
+                out[2] = ds.to(s.dtype)
+        elif need[1] or need[2] or (has_gain and need[3]):
+            # the same through autograd (input_gain needs a gradient too, or the kernels are switched off): the chain rule
             # through the small [N,O,I,k,k] tensor for w, s and input_gain
             with torch.enable_grad():
                 wd = w.detach().requires_grad_(need[1]); sd = s.detach().requires_grad_(need[2])

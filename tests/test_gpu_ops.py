@@ -790,3 +790,24 @@ def test_filtered_lrelu_full_strips_plus_packed_remainder(shape, up, taps, pad, 
         assert first > 0 and nan[0, 1, first, full:].all()           # the whole width of the remainder strip, from the NaN's row on
         assert not nan[0, 1, :, :full].any() and not nan[0, 0].any() and not nan[1:].any()
         assert np.array_equal(yn[~nan], yc[~nan])
+
+
+@pytest.mark.parametrize('n,co,ci,k,demod,gain', [(1, 64, 48, 3, True, 'scalar'), (3, 40, 70, 3, True, 'per_channel'), (2, 33, 17, 1, True, 'per_sample'),
+                                                  (2, 3, 32, 1, False, 'scalar'), (1, 512, 512, 3, True, None), (4, 20, 24, 3, False, None)])
+def test_modulation_backward_kernels_match_autograd(n, co, ci, k, demod, gain):
+    """dL/dw, dL/ds of the effective-weight algebra (pre-normalisation, modulation, demodulation, input gain) in closed form
+    (sg3_modulation_backward, four launches) == autograd through the reference formulation (`_effective_weights`)."""
+    from torch_utils.ops import modulated_conv as mc
+    g = torch.Generator(device=DEV).manual_seed(5)
+    w = torch.randn([co, ci, k, k], device=DEV, generator=g, requires_grad=True)
+    s = (torch.randn([n, ci], device=DEV, generator=g) + 1.0).requires_grad_(True)
+    ig = {None: None, 'scalar': torch.tensor(0.7, device=DEV), 'per_channel': torch.rand([ci], device=DEV, generator=g) + 0.5,
+          'per_sample': torch.rand([n, ci], device=DEV, generator=g) + 0.5}[gain]
+    dw_eff = torch.randn([n, co, ci, k, k], device=DEV, generator=g)
+    w_eff = mc._effective_weights(w, s, demod, ig, n)
+    ref_w, ref_s = torch.autograd.grad(w_eff, [w, s], dw_eff)
+    with torch.no_grad():
+        got_w, got_s = mc._modulation_grads(dw_eff.clone(), w, s, ig, demod)
+    assert got_w.shape == ref_w.shape and got_s.shape == ref_s.shape
+    assert float((got_w - ref_w).abs().max()) <= 2e-5 * max(1e-3, float(ref_w.abs().max()))
+    assert float((got_s - ref_s).abs().max()) <= 2e-5 * max(1e-3, float(ref_s.abs().max()))
