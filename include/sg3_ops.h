@@ -406,6 +406,8 @@ typedef struct sg3_wgrad_params {
     int32_t        k;          /* 1 or 3 */
     int32_t        pad;
     int32_t        nBands, nSegGroups;
+    int32_t        scalesAreAmax; /* 1: *scaleX / *scaleDy hold max |x| / max |dy| and the kernel derives the power-of-two scales
+                                   * itself (2^-ceil(log2(amax / 2^15))): saves the caller eight tiny launches per layer */
 } sg3_wgrad_params;
 
 SG3_API int sg3_conv2d_wgrad_splits(int N, int I, int O, int H, int W, int k, int pad, int* nBands, int* nSegGroups);

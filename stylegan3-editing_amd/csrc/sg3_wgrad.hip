@@ -33,7 +33,14 @@ struct WgradParams {
     const void* x; const void* dy; float* partial; const float* scaleX; const float* scaleDy;
     int N, I, O, H, W, OH, OW, pad;
     int oTiles, iTiles, bandRows, nBands, segsPerGroup, nSegGroups, nSegs;
+    int amax;                        // scaleX / scaleDy point at max |x| / max |dy| instead: the power-of-two scales are derived here
 };
+
+// 2^-e with e = ceil(log2(amax / 2^15)): brings the peak magnitude just below 2^15 (what the caller's torch ops computed:
+// exp2(-ceil(log2(clamp_min(amax, 1e-30) / 32768))))
+__device__ __forceinline__ float pow2_scale(float amax) {
+    return exp2f(-ceilf(log2f(fmaxf(amax, 1e-30f) / 32768.0f)));
+}
 
 template <typename T, int KS>
 __global__ void __launch_bounds__(256, 2)
@@ -60,7 +67,7 @@ wgrad_f16x3_kernel(WgradParams p) {
     const int y0 = band * p.bandRows, y1 = min(y0 + p.bandRows, p.OH);
     const int seg0 = sg * p.segsPerGroup, seg1 = min(seg0 + p.segsPerGroup, p.nSegs);
 
-    const float scD = p.scaleDy[0], scX = p.scaleX[0];
+    const float scD = p.amax ? pow2_scale(p.scaleDy[0]) : p.scaleDy[0], scX = p.amax ? pow2_scale(p.scaleX[0]) : p.scaleX[0];
     const unsigned dyPlane = (unsigned)(p.OH * p.OW) * (unsigned)sizeof(T), xPlane = (unsigned)(p.H * p.W) * (unsigned)sizeof(T);
     const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const T*)p.dy + (size_t)n * p.O * p.OH * p.OW), (short)0, (int)((unsigned)p.O * dyPlane), 0x00020000);
@@ -183,7 +190,7 @@ wgrad_f16x3_kernel(WgradParams p) {
 template <typename T, int KS>
 static int launch_wgrad(const sg3_wgrad_params& q, hipStream_t st) {
     WgradParams p;
-    p.x = q.x; p.dy = q.dy; p.partial = q.partial; p.scaleX = q.scaleX; p.scaleDy = q.scaleDy;
+    p.x = q.x; p.dy = q.dy; p.partial = q.partial; p.scaleX = q.scaleX; p.scaleDy = q.scaleDy; p.amax = q.scalesAreAmax;
     p.N = q.N; p.I = q.I; p.O = q.O; p.H = q.H; p.W = q.W; p.pad = q.pad;
     p.OH = q.H + 2 * q.pad - KS + 1; p.OW = q.W + 2 * q.pad - KS + 1;
     p.oTiles = ceil_div(q.O, 64); p.iTiles = ceil_div(q.I, 64);

@@ -91,7 +91,7 @@ class ModconvPrepParams(ctypes.Structure):
 class WgradParams(ctypes.Structure):
     _fields_ = [('x', c_vp), ('dy', c_vp), ('partial', c_vp), ('scaleX', c_vp), ('scaleDy', c_vp), ('dtype', c_i32),
                 ('N', c_i32), ('I', c_i32), ('O', c_i32), ('H', c_i32), ('W', c_i32), ('k', c_i32), ('pad', c_i32),
-                ('nBands', c_i32), ('nSegGroups', c_i32)]
+                ('nBands', c_i32), ('nSegGroups', c_i32), ('scalesAreAmax', c_i32)]
 
 
 class Conv2dParams(ctypes.Structure):

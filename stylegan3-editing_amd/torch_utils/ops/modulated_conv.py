@@ -240,9 +240,16 @@ def _amax(t):
     return torch.linalg.vector_norm(t.detach().reshape(-1), ord=float('inf')).to(torch.float32).reshape(1)
 
 
-def _pow2_scale(amax):
-    """Device scalar 2^-e with e = ceil(log2(amax / 2^15)): brings the peak magnitude just below 2^15 (fp16 split range)."""
-    return torch.exp2(-torch.ceil(torch.log2(amax.clamp_min(1e-30) / 32768.0)))
+_bound_scalars = {}
+
+
+def _bound_scalar(value, device):
+    """One-element float32 device tensor holding `value` (a layer's input bound), made once per (value, device)."""
+    key = (float(value), str(device))
+    t = _bound_scalars.get(key)
+    if t is None:
+        t = _bound_scalars[key] = torch.full([1], float(value), dtype=torch.float32, device=device)
+    return t
 
 
 def _weight_gradient(x, dy, k, padding, x_amax=None, dy_amax=None):
@@ -255,10 +262,12 @@ def _weight_gradient(x, dy, k, padding, x_amax=None, dy_amax=None):
     nb, ng = ctypes.c_int(), ctypes.c_int()
     abi.check(lib.sg3_conv2d_wgrad_splits(n, ci, co, h, w, k, int(padding), ctypes.byref(nb), ctypes.byref(ng)), 'sg3_conv2d_wgrad_splits')
     partial = torch.empty([nb.value * ng.value, n, k * k, co, ci], dtype=torch.float32, device=x.device)
-    sx = _pow2_scale(x_amax if x_amax is not None else _amax(x))
-    sd = _pow2_scale(dy_amax if dy_amax is not None else _amax(dy))
+    sx = x_amax if x_amax is not None else _amax(x)            # the kernel derives the power-of-two scales from the maxima
+    sd = dy_amax if dy_amax is not None else _amax(dy)
+    sx, sd = sx.to(torch.float32).reshape(1), sd.to(torch.float32).reshape(1)
     p = abi.WgradParams()
     p.x, p.dy, p.partial, p.scaleX, p.scaleDy = abi.ptr(x), abi.ptr(dy), abi.ptr(partial), abi.ptr(sx), abi.ptr(sd)
+    p.scalesAreAmax = 1
     p.dtype = abi.dtype_code(x.dtype)
     p.N, p.I, p.O, p.H, p.W, p.k, p.pad = n, ci, co, h, w, int(k), int(padding)
     p.nBands, p.nSegGroups = nb.value, ng.value
@@ -342,7 +351,7 @@ class _ModulatedConv2dHip(torch.autograd.Function):
             # gradient of the per-sample effective weights (weight-gradient kernel), then the chain rule to w and s in closed form
             x_amax = None
             if ctx.x_bound is not None and ctx.x_bound > 0:
-                x_amax = torch.full([1], float(ctx.x_bound), dtype=torch.float32, device=x.device)     # the layer's own bound: no pass over x
+                x_amax = _bound_scalar(ctx.x_bound, x.device)            # the layer's own bound: no pass over x
             dw_eff = _weight_gradient(x, dy, k, padding, x_amax=x_amax, dy_amax=dy_amax)
             dw, ds = _modulation_grads(dw_eff, w, s, g if has_gain else None, demodulate)
             if need[1]:
@@ -358,7 +367,7 @@ class _ModulatedConv2dHip(torch.autograd.Function):
                 w_eff = _effective_weights(wd.float(), sd.float(), demodulate, gd, n)
             x_amax = None
             if ctx.x_bound is not None and ctx.x_bound > 0:
-                x_amax = torch.full([1], float(ctx.x_bound), dtype=torch.float32, device=x.device)     # the layer's own bound: no pass over x
+                x_amax = _bound_scalar(ctx.x_bound, x.device)            # the layer's own bound: no pass over x
             dw_eff = _weight_gradient(x, dy, k, padding, x_amax=x_amax, dy_amax=dy_amax)
             ins, idx = [], []
             for j, t in ((1, wd), (2, sd), (3, gd)):
