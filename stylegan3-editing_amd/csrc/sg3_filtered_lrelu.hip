@@ -26,6 +26,10 @@
 //   rotation is resolved at compile time by unrolling 6 input rows per loop iteration.
 //   Global reads are issued 3 rows ahead into registers; reads and writes are 256-B contiguous per instruction.
 //   Grid = planes x row-chunks x strips, renumbered so that blocks sharing halo columns/rows sit on one XCD (L2).
+//   Lane fill (plain forward): planes at most 54 columns wide run TWO per wave (template G = 2: lanes 0-31 / 32-63, own LDS
+//   segments, own bias and gain); rows of 120 n + (1..54) columns are cut into n full strips, one plane per wave, plus the
+//   remainder strip with two planes per wave -- in one launch of the G = 2 kernel (StreamParams.wideBlocks) where that costs
+//   no occupancy, in two launches otherwise (`launch_stream`).
 //
 // Supported by the streaming kernel (`stream_supported` / `stream_params_ok` below are the authority): fp32 / fp16 I/O with
 // unit innermost stride, slope in [0,1], and
