@@ -510,12 +510,15 @@ class SynthesisNetwork(torch.nn.Module):
         # of all convolutions is issued as one batch (two launches instead of thirty small, latency-bound ones)
         batched = (self.batch_prep and given.is_cuda and not torch.is_grad_enabled() and not layer_kwargs.get('update_emas', False)
                    and all(k in ('noise_mode', 'force_fp32', 'update_emas') for k in layer_kwargs))
+        # modules whose own forward the merged kernels bypass keep it when somebody hooked them (hooks must keep firing)
+        watched = bool(torch.nn.modules.module._global_forward_hooks) or bool(torch.nn.modules.module._global_forward_pre_hooks) or any(
+            m._forward_hooks or m._forward_pre_hooks for m in [self.input, self.input.affine] + [layer.affine for layer in layers])
         t_in = None
         if all_s is None:
             misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
             per_layer = ws.to(torch.float32).unbind(dim=1)
             styles = None
-            if not (batched and self.input.fast_path_ok()):
+            if not (batched and self.input.fast_path_ok() and not watched):
                 t_in = self.input.transform_params(per_layer[0])
         else:
             t_in = all_s['input']
@@ -524,8 +527,10 @@ class SynthesisNetwork(torch.nn.Module):
         x = None
         if batched:
             n = int(given.shape[0])
-            fast_input = self.input.fast_path_ok()
+            fast_input = self.input.fast_path_ok() and not watched
             normalise = False
+            if styles is None and watched:
+                styles = [layer.styles_from_w(w) for layer, w in zip(layers, per_layer[1:])]
             if styles is None:
                 # every affine layer (the input's and the 15 layers') in one launch instead of ~45 (affine_batch.py)
                 ws32 = ws.to(torch.float32)

@@ -352,3 +352,27 @@ def test_graph_replay_survives_cache_turnover():
         other.synthesis(T(synth_ws(3, other.num_ws, other.w_dim, seed=2)), noise_mode='const', force_fp32=True)
     del junk
     assert maxabs(graphed(ws).cpu().numpy(), want.cpu().numpy()) <= 1e-6
+
+
+def test_hooked_modules_keep_their_own_forward():
+    """GPU inference merges the affine layers and the input's algebra into two kernels that bypass those modules' forward; a
+    module somebody registered a hook on keeps its own forward (the hook fires and sees the module's real output), and the image
+    is the same to rounding."""
+    G = build_product_generator('Ttiny', device=DEV)
+    ws = T(synth_ws(2, G.num_ws, G.w_dim, seed=4))
+    syn = G.synthesis
+    with torch.no_grad():
+        plain = syn(ws, noise_mode='const', force_fp32=True)
+        seen = {}
+        layer = syn.layers()[2]
+        hooks = [layer.affine.register_forward_hook(lambda m, i, o: seen.__setitem__('styles', o.clone())),
+                 syn.input.register_forward_hook(lambda m, i, o: seen.__setitem__('features', o.clone()))]
+        hooked = syn(ws, noise_mode='const', force_fp32=True)
+        for h in hooks:
+            h.remove()
+        again = syn(ws, noise_mode='const', force_fp32=True)
+    assert set(seen) == {'styles', 'features'}
+    assert float((seen['styles'] - layer.affine(ws[:, 3])).abs().max()) == 0.0
+    assert tuple(seen['features'].shape) == (2, syn.input.channels, int(syn.input.size[1]), int(syn.input.size[0]))
+    assert float((hooked - plain).abs().max()) <= 5e-6 * max(1.0, float(plain.abs().max()))
+    assert torch.equal(again, plain)
