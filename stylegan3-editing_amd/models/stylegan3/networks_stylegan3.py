@@ -411,11 +411,23 @@ class SynthesisLayer(torch.nn.Module):
             misc.assert_shape(x, [None, self.out_channels, out_h, out_w])
             return x
         x = filtered_lrelu.filtered_lrelu(
-            x=x, fu=self.up_filter, fd=self.down_filter, b=self.bias.to(x.dtype), up=self.up_factor, down=self.down_factor,
+            x=x, fu=self.up_filter, fd=self.down_filter, b=self._bias_as(x.dtype), up=self.up_factor, down=self.down_factor,
             padding=self.padding, gain=(1 if self.is_torgb else np.sqrt(2)), slope=(1 if self.is_torgb else 0.2), clamp=self.conv_clamp)
         misc.assert_shape(x, [None, self.out_channels, out_h, out_w])
         assert x.dtype == dtype
         return x
+
+    def _bias_as(self, dtype):
+        """The bias in the activations' dtype; the float16 copy of inference is kept until the parameter changes."""
+        b = self.bias
+        if b.dtype == dtype or torch.is_grad_enabled():
+            return b.to(dtype)
+        store = _derived_of(self)
+        key = (b.data_ptr(), b._version, dtype)
+        c = store.get('bias')
+        if c is None or c[0] != key:
+            c = store['bias'] = (key, b.detach().to(dtype))
+        return c[1]
 
     def _track_magnitude(self, x):
         """Running mean of the input's power; its rsqrt is the gain that keeps the convolution input at unit variance."""

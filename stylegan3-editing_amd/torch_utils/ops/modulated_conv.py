@@ -380,10 +380,12 @@ class _ModulatedConv2dHip(torch.autograd.Function):
 
 
 def torgb_epilogue_ok(w, padding, dtype):
-    """True when a call with these weights runs on the ToRGB kernel (1x1, at most 4 output channels, float32), the one
-    kernel that can fuse  clamp(out + bias) * scale  into its stores."""
+    """True when a call with these weights runs on the ToRGB kernel (1x1, at most 4 output channels), the one kernel that can
+    fuse  clamp(out + bias) * scale  into its stores.  float16 tensors (the reference's mixed-precision default) take it too:
+    bias, clamp and scale are then applied to the fp32 accumulator and the result is rounded to fp16 once, where the separate
+    ops round three times."""
     co, ci, k, _ = (int(v) for v in w.shape)
-    return k == 1 and int(padding) == 0 and co <= 4 and ci * 16 <= 48 * 1024 and dtype == torch.float32
+    return k == 1 and int(padding) == 0 and co <= 4 and ci * 16 <= 48 * 1024 and dtype in (torch.float32, torch.float16)
 
 
 @misc.profiled_function
