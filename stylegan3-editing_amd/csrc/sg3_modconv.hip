@@ -1321,8 +1321,20 @@ static int dispatch_conv_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     const int t32 = ceil_div(O, 32) * 32, t64 = ceil_div(O, 64) * 64;
     // last K chunk with 1..4 channels (and at least one full chunk before it): the kernel packs its taps (PACK)
     const bool pack = SG3_TAILPACK && q.I > 16 && q.I % 16 >= 1 && q.I % 16 <= 4;
-    if (O <= 32 || t32 * 10 <= t64 * 9)                                                            //  32 x (16 rows x 32)
+    // The plain fp16 form (one MFMA per K step) reads 0.75 LDS fragments per MFMA with four rows per wave -- LDS-bandwidth bound,
+    // where the split form (0.5 per MFMA, three MFMAs per fragment pair) is not: its waves take taller stacks of rows (six: 0.61; five in the 32-channel tile: 0.67; eight rows spill).
+    // SG3_CONV_F16_ROWS4=1 keeps four rows (A/B timing).
+    static const bool tallF16 = [] { const char* e = getenv("SG3_CONV_F16_ROWS4"); return !(e && e[0] == '1'); }();
+    const bool tall = !SPLIT && tallF16 && q.H + 2 * q.pad - 2 >= 128;
+    if (O <= 32 || t32 * 10 <= t64 * 9) {                                                          //  32 x (16 rows x 32)
+        if constexpr (!SPLIT) {
+            if (tall) return pack ? launch_conv_f16x3<T, 1, 4, 5, SPLIT, true>(q, st) : launch_conv_f16x3<T, 1, 4, 5, SPLIT, false>(q, st);
+        }
         return pack ? launch_conv_f16x3<T, 1, 4, 4, SPLIT, true>(q, st) : launch_conv_f16x3<T, 1, 4, 4, SPLIT, false>(q, st);
+    }
+    if constexpr (!SPLIT) {
+        if (tall) return pack ? launch_conv_f16x3<T, 2, 2, 6, SPLIT, true>(q, st) : launch_conv_f16x3<T, 2, 2, 6, SPLIT, false>(q, st);
+    }
     // Narrow outputs with 64-channel tiles: runs of the flattened plane instead of 32-column row pieces (modconv_flat_kernel) when
     // that takes fewer rounds x MFMA blocks per wave than the best row tile.  SG3_CONV3_ROWS=1 keeps the row kernel.
     if (!pack && (q.outRowStride == 0 || q.outRowStride == q.W + 2 * q.pad - 2) && conv3_use_flat()) {

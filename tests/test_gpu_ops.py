@@ -451,10 +451,12 @@ def test_modulated_conv2d_split_precision_1x1(n, ci, co, h):
     assert yh.dtype == torch.float16 and maxabs(yh.float().cpu().numpy(), refh) <= 2e-3 * max(1.0, float(np.abs(refh).max()))
 
 
-@pytest.mark.parametrize('n,ci,co,h,k', [(2, 203, 128, 37, 3), (1, 81, 51, 50, 3), (2, 645, 406, 20, 1), (1, 64, 64, 33, 1)])
+@pytest.mark.parametrize('n,ci,co,h,k', [(2, 203, 128, 37, 3), (1, 81, 51, 50, 3), (2, 645, 406, 20, 1), (1, 64, 64, 33, 1),
+                                         (1, 64, 128, 131, 3), (1, 51, 32, 140, 3), (1, 81, 51, 127, 3), (1, 33, 70, 150, 3)])
 def test_modulated_conv2d_fp16_form(n, ci, co, h, k):
     """fp16 tensors take the single-MFMA fp16 form (SG3_CONV_F16): equal to the fp64 result for operands rounded to
-    fp16 up to fp16 rounding of (x * s), of the weights and of the output."""
+    fp16 up to fp16 rounding of (x * s), of the weights and of the output.  Outputs of 128 rows or more take the taller row
+    stacks of that form (six rows per wave in the 64-channel tile, five in the 32-channel one, with and without the packed K tail)."""
     from oracle import oracle as O
     from torch_utils.ops import modulated_conv as mc
     x = np.clip(rand(91, n, ci, h, h + 3) * 20, -256, 256).astype(np.float16); w = rand(92, co, ci, k, k); s = rand(93, n, ci) + 1
