@@ -311,7 +311,15 @@ enum {
     SG3_CONV_F16   = 2,  /* operands rounded to fp16 once, one v_mfma_f32_32x32x16_f16 per K step, fp32 accumulation:
                           * the arithmetic of the reference's fp16 layers (networks_stylegan3.py:59-62 with fp16 x and
                           * w.to(x.dtype)); same packing, xBound and power-of-two rescale as SG3_CONV_F16X3 */
+    SG3_CONV_F16X3_F23 = 3, /* SG3_CONV_F16X3 in a transform domain along x (Winograd F(2,3): per pair of output columns four
+                          * transform points of a 3-tap vertical filter instead of 2 x 9 taps): two thirds of the matrix
+                          * instructions, the same split arithmetic on the transformed operands (inputs transformed in fp32 before
+                          * the split, weights at pack time).  3x3 kernels on fp32 tensors with even W, pad and output row pitch
+                          * only (sg3_modconv_f23_supported); its own packed layout, so prep and convolution must agree */
 };
+
+/* 1 when sg3_modulated_conv2d takes this call with precision SG3_CONV_F16X3_F23 (host-only query, no launch) */
+SG3_API int sg3_modconv_f23_supported(int dtype, int I, int O, int H, int W, int k, int pad, int outRowStride);
 
 /* number of floats (4-byte units) of the packed weight buffer for an [O,I,k,k] weight
  * (fp32: [O][ceil(I/KC)][k*k][KC] floats; f16x3 / f16: [O][chunks][k*k][hi|lo][16] halfs, chunks = ceil(I/16), rounded up to even for k = 1; zero padded). */

@@ -25,6 +25,7 @@
 // demodulation (dcoef) is applied in the epilogue; bias/activation belong to the following filtered_lrelu.
 #include "sg3_common.h"
 #include "sg3_split.h"
+#include "sg3_modconv_f23.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -1006,6 +1007,10 @@ modconv1_f16x3_kernel(ConvParams p) {
 // 1x1 kernels with very few output channels (the ToRGB layer: 32 -> 3): HBM-bound, no matrix cores.
 // out[n,o,p] = dcoef[n,o] * sum_i wn[o,i] * sIn[n,i] * x[n,i,p]; a thread owns 4 consecutive pixels (16-byte loads
 // per channel plane), the modulated weights sit in LDS.
+// clamp of the fused ToRGB output stage: a NaN stays a NaN, as through the reference's clamp (filtered_lrelu.cu:412-419 /
+// bias_act.cu: `if (fabsf(v) > clamp) v = copysign(clamp, v)`); fminf / fmaxf alone return the finite operand
+static __device__ __forceinline__ float ep_clamp(float v, float c) { return v != v ? v : fminf(fmaxf(v, -c), c); }
+
 template <typename T, int OMAX>
 __global__ void __launch_bounds__(256)
 modconv_1x1_small_kernel(ConvParams p, int vec) {
@@ -1041,7 +1046,7 @@ modconv_1x1_small_kernel(ConvParams p, int vec) {
                 if (p.epBias) {
                     const float bo = p.epBias[o];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) acc[o][e] = fminf(fmaxf(acc[o][e] + bo, -p.epClamp), p.epClamp) * p.epScale;
+                    for (int e = 0; e < 4; e++) acc[o][e] = ep_clamp(acc[o][e] + bo, p.epClamp) * p.epScale;
                 }
                 if (sizeof(T) == 4) *reinterpret_cast<f32x4*>(outp + (size_t)o * HW + q * 4) = (f32x4){acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
                 else for (int e = 0; e < 4; e++) io<T>::st(outp + (size_t)o * HW + q * 4 + e, acc[o][e]);
@@ -1058,7 +1063,7 @@ modconv_1x1_small_kernel(ConvParams p, int vec) {
                 for (int o = 0; o < OMAX; o++) acc[o] = fmaf(sw[i * OMAX + o], xv, acc[o]);
             }
             for (int o = 0; o < p.O && o < OMAX; o++) {
-                if (p.epBias) acc[o] = fminf(fmaxf(acc[o] + p.epBias[o], -p.epClamp), p.epClamp) * p.epScale;
+                if (p.epBias) acc[o] = ep_clamp(acc[o] + p.epBias[o], p.epClamp) * p.epScale;
                 io<T>::st(outp + (size_t)o * HW + q, acc[o]);
             }
         }
@@ -1098,7 +1103,9 @@ static __device__ __forceinline__ void prep_w_body(const sg3_modconv_prep_params
         for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
         scale = rsqrtf(red[0] / (float)len);
     }
-    if (p.precision != SG3_CONV_FP32) {
+    if (p.precision == SG3_CONV_F16X3_F23) {
+        f23_pack_row(w, scale, o, p.O, p.I, nch, reinterpret_cast<_Float16*>(p.wPacked));      // transform-domain layout (sg3_modconv_f23.h)
+    } else if (p.precision != SG3_CONV_FP32) {
         // [o][chunk][tap][hi|lo][16] halfs
         _Float16* dsth = reinterpret_cast<_Float16*>(p.wPacked) + (size_t)o * nch * taps * 32;
         for (int j = threadIdx.x; j < nch * taps * 16; j += 256) {
@@ -1185,6 +1192,7 @@ static __device__ __forceinline__ void prep_s_body(const sg3_modconv_prep_params
         const float peak = red[0] * (p.xBoundDev ? p.xBoundDev[0] : p.xBound);
         int e = 0;
         if (peak > 0.f && peak < 3.0e38f) e = (int)ceilf(log2f(peak / 32768.f));    // either direction: tiny operands (gradients) are scaled up
+        if (p.precision == SG3_CONV_F16X3_F23) e += 1;                               // the input transform forms sums of two samples
         down = ldexpf(1.f, -e); up = ldexpf(1.f, e);
     }
     __syncthreads();
@@ -1420,6 +1428,7 @@ extern "C" {
 
 int64_t sg3_modconv_packed_floats(int O, int I, int k, int precision) {
     if (O <= 0 || I <= 0 || (k != 1 && k != 3)) return 0;
+    if (precision == SG3_CONV_F16X3_F23) return k == 3 ? sg3::f23_packed_floats(O, I) : 0;
     if (precision == SG3_CONV_F16X3 || precision == SG3_CONV_F16) {
         return (int64_t)O * sg3::f16x3_chunks(I, k) * (k * k) * 16;   // 32 halfs = 16 floats per (chunk, tap)
     }
@@ -1436,11 +1445,17 @@ static int prep_validate(const sg3_modconv_prep_params* p) {
     SG3_REQUIRE(p->inputGainMode >= 0 && p->inputGainMode <= 3, "modulated_conv2d_prep: bad inputGainMode");
     SG3_REQUIRE(p->inputGainMode == 0 || p->inputGain, "modulated_conv2d_prep: inputGain missing");
     SG3_REQUIRE((size_t)p->I * 2 * sizeof(float) <= 48 * 1024, "modulated_conv2d_prep: too many input channels");
-    SG3_REQUIRE(p->precision == SG3_CONV_FP32 || p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16, "modulated_conv2d_prep: bad precision");
+    SG3_REQUIRE(p->precision == SG3_CONV_FP32 || p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16 || p->precision == SG3_CONV_F16X3_F23,
+                "modulated_conv2d_prep: bad precision");
+    SG3_REQUIRE(p->precision != SG3_CONV_F16X3_F23 || p->k == 3, "modulated_conv2d_prep: the transform-domain form is for 3x3 kernels");
     if (p->precision != SG3_CONV_FP32) {
         SG3_REQUIRE((p->xBound > 0.f || p->xBoundDev) && p->dcoef, "modulated_conv2d_prep: f16x3 needs xBound > 0 and a dcoef buffer");
     }
     return SG3_OK;
+}
+
+int sg3_modconv_f23_supported(int dtype, int I, int O, int H, int W, int k, int pad, int outRowStride) {
+    return sg3::f23_supported(dtype, I, O, H, W, k, pad, outRowStride) ? 1 : 0;
 }
 
 int sg3_modulated_conv2d_prep_batch(const sg3_modconv_prep_params* list, int count, void* stream) {
@@ -1502,12 +1517,18 @@ int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     {
         const int outW = p->W + 2 * p->pad - p->k + 1;
-        const bool rowStream = p->k == 3 && (p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16);
+        const bool rowStream = p->k == 3 && (p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16 || p->precision == SG3_CONV_F16X3_F23);
         SG3_REQUIRE(p->outRowStride == 0 || p->outRowStride == outW || (rowStream && p->outRowStride > outW),
                     "modulated_conv2d: outRowStride must be 0 or outW (a larger pitch is supported by the 3x3 f16x3 / f16 kernels only)");
     }
     const bool torgb = p->precision == SG3_CONV_FP32 && p->k == 1 && p->pad == 0 && p->O <= 4 && (size_t)p->I * 4 * sizeof(float) <= 48 * 1024;
     SG3_REQUIRE(!p->epilogueBias || torgb, "modulated_conv2d: the bias / clamp / scale epilogue exists for the ToRGB kernel only (1x1, O <= 4, fp32 form)");
+    if (p->precision == SG3_CONV_F16X3_F23) {
+        SG3_REQUIRE(p->dcoef, "modulated_conv2d: f16x3 needs dcoef");
+        SG3_REQUIRE(f23_supported(p->dtype, p->I, p->O, p->H, p->W, p->k, p->pad, p->outRowStride),
+                    "modulated_conv2d: SG3_CONV_F16X3_F23 takes 3x3 kernels on fp32 tensors with even W, pad and row pitch (sg3_modconv_f23_supported)");
+        return launch_conv_f23(*p, st);
+    }
     if (p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16) {
         SG3_REQUIRE(p->dcoef, "modulated_conv2d: f16x3 needs dcoef");
         SG3_REQUIRE(p->k == 3 || p->pad == 0, "modulated_conv2d: f16x3 1x1 kernels take no padding");

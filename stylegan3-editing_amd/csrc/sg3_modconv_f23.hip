@@ -1,0 +1,456 @@
+// sg3_modconv_f23.hip -- the 3x3 modulated convolution in a TRANSFORM DOMAIN along x (Winograd F(2,3)), split precision:
+// 12 instead of 18 channel contractions per pair of output pixels, i.e. two thirds of the matrix instructions of
+// modconv_f16x3_kernel at the same fp32-equivalent arithmetic.  Same operation as sg3_modconv.hip
+// (reference models/stylegan3/networks_stylegan3.py:24-63, the grouped F.conv2d at :59-62):
+//
+//     out[n,o,y,x] = dcoef[n,o] * sum_{i,ky,kx} wn[o,i,ky,kx] * ( x[n,i,y+ky-pad,x+kx-pad] * sIn[n,i] )
+//
+// For an output pixel PAIR (columns 2p, 2p+1) with the four input columns d0..d3 = 2p-pad .. 2p-pad+3 of input row y+ky-pad:
+//     V0 = d0 - d2    V1 = d1 + d2    V2 = d2 - d1    V3 = d1 - d3              (input transform, fp32, before the split)
+//     U0 = g0         U1 = (g0+g1+g2)/2   U2 = (g0-g1+g2)/2   U3 = g2            (weight transform of a filter row g, at pack time)
+//     M_xi[o, y, p] = sum_{ky, i} U_xi[o,i,ky] * V_xi[i, y+ky, p]                (the matrix-core work: K = 3 I per xi)
+//     out(2p) = M0 + M1 + M2      out(2p+1) = M1 - M2 - M3                       (output transform, once per tile)
+// Each V and U value is split into fp16 hi + lo and every 16-channel K step runs three v_mfma_f32_32x32x16_f16
+// (Uh Vh + Uh Vl + Ul Vh), exactly as the direct kernel does with x and w.
+//
+// Work split (one 512-thread workgroup per CU, 8 waves): wave = (xi, M block): it owns ONE transform point for 32 output
+// channels and the whole pixel tile, so a wave touches a quarter of the weight image and keeps ONE accumulator set
+// (TN x 16 registers); the four xi-waves of an M block meet once per tile, in the output transform, through LDS.
+// Pixel tile: 2 TN rows x 16 pairs (32 output columns): the MFMA's 32 columns are (row group rg = 0 | 1) x 16 pairs, lanes of
+// row group 1 sitting TN rows below those of group 0 -- a uniform address shift per patch row, so one B fragment (patch row q)
+// serves the three output rows q, q-1, q-2 of BOTH groups, as in the row-streaming direct kernel: 2 ds_read_b128 per 9 MFMAs.
+// A fragments (U) never pass through LDS: the pack kernel writes them in MFMA lane order per (M tile, chunk, M block, xi), and
+// a wave loads its six 1 KB fragments of the next chunk straight into registers (a 6 KB contiguous run, L2 resident).
+// B image (V): [xi][hi|lo][channel half][patch row][pair][8 channels] halfs, double buffered; staged by all waves: a thread
+// owns (patch row, pair, channel half), loads 8 channels x 4 columns (two 8-byte loads per channel), transforms, splits and
+// writes eight 16-byte vectors.  One barrier per 16-channel chunk.  Waves 4-7 (the second wave of every SIMD) run the
+// chunk body in the order stage-then-MFMA, waves 0-3 MFMA-then-stage, so that one wave's staging arithmetic sits beside the
+// other's matrix instructions instead of both waves alternating in lockstep.
+#include "sg3_common.h"
+#include "sg3_split.h"
+#include "sg3_modconv_f23.h"
+#include <cstdlib>
+
+namespace sg3 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct F23Params {
+    const float* x; const void* wp; const float* sIn; const float* dcoef; float* out;
+    int N, I, O, H, W, outH, outW, pad;
+    int nch, xTiles, yTiles, mTiles, totalBlocks, outPitch;
+#ifdef SG3_F23_STAMPS
+    unsigned long long* stamps;      // diagnostic build (tools/f23_stamps.hip): [workgroup][wave][8] cycle sums, never in the product library
+#endif
+};
+
+#ifdef SG3_F23_STAMPS
+unsigned long long* g_f23_stamps = nullptr;
+#define F23_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define F23_STAMP(t) do { } while (0)
+#endif
+
+template <int TN>
+__global__ void __launch_bounds__(512, 2)
+modconv_f23_kernel(F23Params p) {
+    constexpr int PR = 2 * TN + 2;                     // patch rows of a tile
+    constexpr int PLANE = PR * 256;                    // bytes per (xi, part, channel half) plane: rows of 16 pairs x 16 B
+    constexpr int BUF = 16 * PLANE;                    // 4 xi x (hi | lo) x 2 channel halves
+    constexpr int FRAG = 1024;                         // bytes per A fragment (64 lanes x 16 B)
+    constexpr int CHUNKB = 2 * 4 * 6 * FRAG;           // packed weights per (M tile, chunk): 2 M blocks x 4 xi x (3 ky x hi|lo)
+    static_assert(PR <= 16, "staging map: 8 waves x 2 (row, channel half) pairs");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];           // 2 x BUF (>= 64 KB: the exchange area of the output transform)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xi = wave & 3, mb = wave >> 2;
+    const int li = lane & 31, lh = lane >> 5;
+    const int rg = li >> 4, pq = li & 15;
+
+    int bid = blockIdx.x;
+    {
+        const int nb = p.totalBlocks, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int mt = bid % p.mTiles; bid /= p.mTiles;
+    const int xt = bid % p.xTiles; bid /= p.xTiles;
+    const int yt = bid % p.yTiles; const int n = bid / p.yTiles;
+    const int o0 = mt * 64, x0 = xt * 32, y0 = yt * (2 * TN);
+
+    // ---- descriptors, as SGPR quads for the hand-issued loads below ----
+    const unsigned HWb = (unsigned)(p.H * p.W) * 4u;
+    auto make_desc = [](const void* base, unsigned bytes) {
+        const unsigned long long a = (unsigned long long)base;
+        u32x4 d;
+        d.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+        d.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);           // stride 0
+        d.z = __builtin_amdgcn_readfirstlane(bytes);
+        d.w = 0x00020000u;
+        return d;
+    };
+    const u32x4 xd = make_desc(p.x + (size_t)n * p.I * p.H * p.W, (unsigned)p.I * HWb);
+    const u32x4 wd = make_desc(p.wp, (unsigned)p.mTiles * (unsigned)p.nch * (unsigned)CHUNKB);
+    const u32x4 sd = make_desc(p.sIn + (size_t)n * p.I, (unsigned)p.I * 4u);
+
+    // ---- staging task of this thread: (patch row, pair, channel half) ----
+    const int sch = wave & 1;                                         // wave-uniform channel half
+    const int srow = (wave >> 1) * 4 + (lane >> 4);
+    const int spair = lane & 15;
+    const bool sOk = srow < PR;
+    unsigned g0, g1;                                                  // byte offsets of columns (2p, 2p+1) and (2p+2, 2p+3) in a channel plane
+    {
+        const int gy = y0 - p.pad + srow, gx = x0 - p.pad + 2 * spair;
+        const bool rowOk = sOk && (unsigned)gy < (unsigned)p.H;
+        g0 = rowOk && (unsigned)gx < (unsigned)p.W ? (unsigned)(gy * p.W + gx) * 4u : 0x80000000u;
+        g1 = rowOk && (unsigned)(gx + 2) < (unsigned)p.W ? (unsigned)(gy * p.W + gx + 2) * 4u : 0x80000000u;
+    }
+    const unsigned gS = (unsigned)(lane & 15) * 4u;                   // style scales: lane c requests channel c of the chunk
+    const int sL = srow * 256 + spair * 16 + sch * PLANE;             // + (xi * 2 + part) * 2 * PLANE
+    // ---- A: this wave's six fragments of a chunk ----
+    const unsigned aG = (unsigned)((mb * 4 + xi) * 6) * FRAG + (unsigned)lane * 16u;
+    const unsigned aS = (unsigned)mt * (unsigned)p.nch * (unsigned)CHUNKB;             // + chunk * CHUNKB + fragment * FRAG (scalar offset)
+    // ---- B fragment reads ----
+    const int bR = (xi * 4 + lh) * PLANE + (rg * TN) * 256 + pq * 16;  // hi plane of this lane's channel half; lo at + 2 PLANE
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int b = 0; b < TN; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[b][r] = 0.f;
+
+    // All vector-memory loads of the K loop are issued and waited for BY HAND (inline asm): the two request streams -- A fragments
+    // of the next chunk, input samples of the chunk after -- are consumed in a different order than they are issued, and hipcc,
+    // merging the loop's paths, drains the whole queue (s_waitcnt vmcnt(0)) in front of each consumer, i.e. waits for the loads it
+    // has just issued: 1800-2700 cycles per staging block instead of ~600 (in-kernel stamps, profiles/r03_f23_stamps.txt).  The
+    // counter is in order, so "all but the N youngest" is exact: N = the loads issued after the group that is needed.  Every wait
+    // statement names the destination registers as read-write operands, which keeps their consumers behind it.
+    f32x2 rb[8][2];
+    float rsc;
+    u32x4 af[6];                                                      // A fragments of the current chunk: (ky, hi | lo)
+    constexpr int NB = 17, NA = 6;                                    // loads per input request / per fragment request
+
+    // Requests are issued on EVERY iteration -- beyond the last chunk with an out-of-range offset, which the range check answers with
+    // zeros without touching memory -- so the queue has the same shape in every iteration (constant wait counts) and the registers
+    // are redefined on every path (no copies of in-flight destinations: see the audit note at the waits).
+    auto fetch_a = [&](int ch) {
+        const unsigned so = aS + (unsigned)ch * CHUNKB;               // wave-uniform
+        const unsigned vo = ch < p.nch ? aG : 0x80000000u;
+#if defined(SG3_F23_BUILTIN) || defined(SG3_F23_BUILTIN_A)
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, (short)0, (int)((unsigned)p.mTiles * (unsigned)p.nch * (unsigned)CHUNKB), 0x00020000);
+#pragma unroll
+        for (int f = 0; f < 6; f++) af[f] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)vo, (int)(so + f * FRAG), 0);
+#else
+#pragma unroll
+        for (int f = 0; f < 6; f++)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(af[f]) : "v"(vo), "s"(wd), "s"(so + f * FRAG) : "memory");
+#endif
+    };
+    auto fetch_b = [&](int ch) {
+        const bool in = ch < p.nch;
+        // the chunk's channel offset rides in the VECTOR offset of the scale request: only that is range checked, and channels beyond I
+        // must read a zero scale (they alias channel 0 of the input)
+        const unsigned v0 = in ? g0 : 0x80000000u, v1 = in ? g1 : 0x80000000u, vs = in ? gS + (unsigned)ch * 64u : 0x80000000u;
+#if defined(SG3_F23_BUILTIN) || defined(SG3_F23_BUILTIN_B)
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * p.I * p.H * p.W), (short)0, (int)((unsigned)p.I * HWb), 0x00020000);
+        const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.sIn + (size_t)n * p.I), (short)0, p.I * 4, 0x00020000);
+        rsc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, (int)vs, 0, 0));
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int ci = ch * 16 + sch * 8 + c;
+            const unsigned coff = ci < p.I ? (unsigned)ci * HWb : 0u;
+            rb[c][0] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)v0, (int)coff, 0));
+            rb[c][1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)v1, (int)coff, 0));
+        }
+#else
+        asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(rsc) : "v"(vs), "s"(sd) : "memory");
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int ci = ch * 16 + sch * 8 + c;                       // wave-uniform
+            const unsigned coff = ci < p.I ? (unsigned)ci * HWb : 0u;   // padded channels alias channel 0 and meet a zero scale
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(rb[c][0]) : "v"(v0), "s"(xd), "s"(coff) : "memory");
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(rb[c][1]) : "v"(v1), "s"(xd), "s"(coff) : "memory");
+        }
+#endif
+    };
+    // AUDIT after every edit (tools/audit_f23_asm.py on the -save-temps .s): between a hand-issued load and the wait that covers it
+    // hipcc must not read or copy the destination registers (it treats them as written when the load is issued).
+#ifdef SG3_F23_WAIT0
+#define F23_CNT(N) "0"
+#else
+#define F23_CNT(N) #N
+#endif
+#if defined(SG3_F23_BUILTIN) || defined(SG3_F23_BUILTIN_A)
+#define F23_WAIT_A(N) do { } while (0)
+#else
+#define F23_WAIT_A(N) asm volatile("s_waitcnt vmcnt(" F23_CNT(N) ")" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]) :: "memory")
+#endif
+#if defined(SG3_F23_BUILTIN) || defined(SG3_F23_BUILTIN_B)
+#define F23_WAIT_B(N) do { } while (0)
+#else
+#define F23_WAIT_B(N) asm volatile("s_waitcnt vmcnt(" F23_CNT(N) ")" : "+v"(rsc), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]), \
+        "+v"(rb[3][0]), "+v"(rb[3][1]), "+v"(rb[4][0]), "+v"(rb[4][1]), "+v"(rb[5][0]), "+v"(rb[5][1]), "+v"(rb[6][0]), "+v"(rb[6][1]), "+v"(rb[7][0]), "+v"(rb[7][1]) :: "memory")
+#endif
+    static_assert(NB == 17 && NA == 6, "the wait counts below are written for these request sizes");
+
+    auto stage = [&](int buf) {
+        // Per channel: t = s (d2, d3);  (V0, V3) = s (d0, d1) - t;  (V1, V2) = (s d1 + t.x, t.x - s d1): three packed instructions
+        // (the style scale rides in the multiplies; halves picked with op_sel).  Per transform point and channel pair: hi = the two
+        // values truncated to fp16 (v_cvt_pkrtz), lo = fp16(value - hi) by v_fma_mixlo / mixhi: three more.
+        f32x2 v03[8], v12[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+#ifdef SG3_F23_CSTAGE
+            const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rsc), sch * 8 + c));
+            const float d0 = rb[c][0].x * sc, d1 = rb[c][0].y * sc, d2 = rb[c][1].x * sc, d3 = rb[c][1].y * sc;
+            v03[c] = (f32x2){d0 - d2, d1 - d3}; v12[c] = (f32x2){d1 + d2, d2 - d1};
+#else
+            const unsigned long long sc2 = (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, rsc), sch * 8 + c);   // low half: the scale
+            f32x2 t;
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(rb[c][1]), "s"(sc2));
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(v03[c]) : "v"(rb[c][0]), "s"(sc2), "v"(t));
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] neg_hi:[1,0,0]" : "=v"(v12[c]) : "v"(rb[c][0]), "s"(sc2), "v"(t));
+#endif
+        }
+        unsigned char* dst = sm + buf * BUF + sL;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            u32x4 hv, lv;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float x0 = t == 0 ? v03[2 * c].x : (t == 1 ? v12[2 * c].x : (t == 2 ? v12[2 * c].y : v03[2 * c].y));
+                const float x1 = t == 0 ? v03[2 * c + 1].x : (t == 1 ? v12[2 * c + 1].x : (t == 2 ? v12[2 * c + 1].y : v03[2 * c + 1].y));
+#ifdef SG3_F23_CSPLIT
+                v2h h2, l2;
+                split2(x0, x1, h2, l2);
+                const unsigned h = __builtin_bit_cast(unsigned, h2), l = __builtin_bit_cast(unsigned, l2);
+#else
+                const unsigned h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+                unsigned l;
+                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=&v"(l) : "v"(h), "v"(x0));
+                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x1));
+#endif
+                hv[c] = h; lv[c] = l;
+            }
+            if (sOk) {
+                *reinterpret_cast<u32x4*>(dst + (t * 4) * PLANE) = hv;
+                *reinterpret_cast<u32x4*>(dst + (t * 4 + 2) * PLANE) = lv;
+            }
+        }
+    };
+    struct BFrag { v8h h, l; };
+    auto load_b = [&](BFrag& f, int buf, int q) {
+        const unsigned char* src = sm + buf * BUF + bR + q * 256;
+        f.h = *reinterpret_cast<const v8h*>(src);
+        f.l = *reinterpret_cast<const v8h*>(src + 2 * PLANE);
+    };
+    auto mfma_row = [&](const BFrag& f, int q) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) { const int b = q - ky; if (b >= 0 && b < TN) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, af[2 * ky + 1]), f.h, acc[b], 0, 0, 0); }
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) { const int b = q - ky; if (b >= 0 && b < TN) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, af[2 * ky]), f.l, acc[b], 0, 0, 0); }
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) { const int b = q - ky; if (b >= 0 && b < TN) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, af[2 * ky]), f.h, acc[b], 0, 0, 0); }
+    };
+    // an M block of pure channel padding (O = 203: channels 224..255 of the fourth tile) stages and synchronises but issues no MFMAs
+    const bool active = o0 + mb * 32 < p.O;                                  // wave-uniform
+    auto mfma_chunk = [&](int buf) {
+        if (!active) return;
+        __builtin_amdgcn_s_setprio(1);
+        BFrag b0, b1;
+        load_b(b0, buf, 0);
+#pragma unroll
+        for (int q = 0; q < TN + 2; q += 2) {
+            if (q + 1 < TN + 2) load_b(b1, buf, q + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_row(b0, q);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < TN + 2) {
+                if (q + 2 < TN + 2) load_b(b0, buf, q + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_row(b1, q + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // Chunk body: MFMA loop on chunk ch (B image buf = ch & 1, fragments af) and staging of chunk ch + 1 into the other image.
+    //   waves 0-3 ("early"):  wait A(ch) | MFMA(ch) | request A(ch+1) | wait B(ch+1) | stage(ch+1) | request B(ch+2) | barrier
+    //   waves 4-7 ("late"):   wait B(ch+1) | stage(ch+1) | request B(ch+2) | wait A(ch) | MFMA(ch) | request A(ch+1) | barrier
+    // so on every SIMD one wave's staging arithmetic runs beside the other's matrix instructions.  The fragments of chunk ch + 1 go
+    // into the registers chunk ch has just released: a staging block (the wave's own, in either order) lies between the request and
+    // the first use, which hides the L2 latency without a second register set.
+    // Load queue (oldest first) when an iteration starts -- early: A(ch), B(ch+1);  late: B(ch+1), A(ch).
+    const bool late = wave >= 4;                                             // wave-uniform: second wave of its SIMD
+    const int nch = p.nch;
+    if (!late) fetch_a(0);
+    fetch_b(0);
+    F23_WAIT_B(0);
+    stage(0);
+    fetch_b(1);
+    if (late) fetch_a(0);
+    __syncthreads();
+#ifdef SG3_F23_STAMPS
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, sPre = 0, sMfma = 0, sPost = 0, sBar = 0, tStart, rStart;
+    F23_STAMP(tStart);
+    rStart = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int ch = 0; ch < nch; ch++) {
+        const int buf = ch & 1;
+        const bool more1 = ch + 1 < nch;
+        F23_STAMP(tA);
+        // ONE MFMA site in the loop (the accumulators must not become a phi of two branches: hipcc then keeps two copies of them)
+        if (late) {
+            F23_WAIT_B(6);                                                   // younger: A(ch)
+            if (more1) stage(buf ^ 1);
+            fetch_b(ch + 2);
+        }
+        F23_WAIT_A(17);                                                      // younger: B(ch+1) (early) / B(ch+2) (late)
+#ifdef SG3_F23_DUMPA
+        if (blockIdx.x == 0) {                                               // diagnostic: what the fragments hold after the wait
+            unsigned* o = reinterpret_cast<unsigned*>(p.stamps) + 4096 + ((((size_t)ch * 8 + wave) * 6) * 64 + lane) * 4;
+#pragma unroll
+            for (int f = 0; f < 6; f++) { o[f * 256 + 0] = af[f].x; o[f * 256 + 1] = af[f].y; o[f * 256 + 2] = af[f].z; o[f * 256 + 3] = af[f].w; }
+        }
+#endif
+        F23_STAMP(tB);
+        mfma_chunk(buf);
+        F23_STAMP(tC);
+#ifdef SG3_F23_DRAIN_MFMA
+        {   // experiment: no fragment request before the matrix pipe has executed this chunk's last instruction
+            float t = acc[TN - 1][15];
+            asm volatile("v_mov_b32 %0, %0" : "+v"(t));
+            acc[TN - 1][15] = t;
+        }
+#endif
+        fetch_a(ch + 1);
+        if (!late) {
+            F23_WAIT_B(6);                                                   // younger: A(ch+1)
+            if (more1) stage(buf ^ 1);
+            fetch_b(ch + 2);
+        }
+        F23_STAMP(tD);
+        __syncthreads();
+#ifdef SG3_F23_STAMPS
+        F23_STAMP(tE);
+        sPre += tB - tA; sMfma += tC - tB; sPost += tD - tC; sBar += tE - tD;
+#endif
+    }
+    // The last requests (beyond the last chunk) are never consumed, but their destination registers stay RESERVED until they have
+    // landed: the waits name them.  (An operand-less s_waitcnt here let hipcc reuse v64 / v68 for the epilogue's addresses before the
+    // wait, and the returning zeros overwrote them -- wrong stores from whichever waves lost that race.)
+    F23_WAIT_B(0);
+    F23_WAIT_A(0);
+#ifdef SG3_F23_STAMPS
+    if (p.stamps && lane == 0) {
+        unsigned long long tEnd; F23_STAMP(tEnd);
+        const unsigned long long rEnd = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[0] = sPre; o[1] = sMfma; o[2] = sPost; o[3] = sBar; o[4] = tEnd - tStart; o[5] = rEnd - rStart;
+    }
+#endif
+
+    // ---- output transform: the four xi-waves of an M block exchange their accumulators through LDS, one tile row pair at a time ----
+    // wave (xi, mb) finishes accumulator registers 4 xi .. 4 xi + 3 = channels o0 + 32 mb + 8 xi + 4 lh + j of all 32 columns
+    float* X = reinterpret_cast<float*>(sm);                                  // [2][8 waves][16 registers][64 lanes]
+    const int oc = o0 + mb * 32 + 8 * xi + 4 * lh;
+    float d[4];
+    {
+        const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dcoef + (size_t)n * p.O), (short)0, p.O * 4, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; j++) d[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, (oc + j) * 4, 0, 0));
+    }
+    const unsigned planeB = (unsigned)(p.outH * p.outPitch) * 4u;
+    const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.out + (size_t)n * p.O * p.outH * p.outPitch), (short)0, (int)((unsigned)p.O * planeB), 0x00020000);
+    const int gx = x0 + 2 * pq;
+    const unsigned colOff = gx < p.outW ? (unsigned)oc * planeB + (unsigned)gx * 4u : 0x80000000u;
+#pragma unroll
+    for (int b = 0; b < TN; b++) {
+        float* Xb = X + (b & 1) * (8 * 16 * 64);
+#pragma unroll
+        for (int r = 0; r < 16; r++) Xb[(wave * 16 + r) * 64 + lane] = acc[b][r];
+        __syncthreads();
+        const int gy = y0 + rg * TN + b;
+        const unsigned rowOff = gy < p.outH ? colOff + (unsigned)(gy * p.outPitch) * 4u : 0x80000000u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float* src = Xb + ((mb * 4) * 16 + 4 * xi + j) * 64 + lane;
+            const float m0 = src[0], m1 = src[16 * 64], m2 = src[2 * 16 * 64], m3 = src[3 * 16 * 64];
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const float ya = (m0 + m1 + m2) * d[j], yb = (m1 - m2 - m3) * d[j];
+            const u32x2 v = {__builtin_bit_cast(unsigned, ya), __builtin_bit_cast(unsigned, yb)};
+            __builtin_amdgcn_raw_buffer_store_b64(v, orr, (int)(rowOff + (unsigned)j * planeB), 0, 0);
+        }
+    }
+}
+
+int64_t f23_packed_floats(int O, int I) {
+    return (int64_t)ceil_div(O, 64) * ceil_div(I, 16) * (2 * 4 * 6 * 1024 / 4);
+}
+
+bool f23_supported(int dtype, int I, int O, int H, int W, int k, int pad, int outRowStride) {
+    if (k != 3 || dtype != SG3_F32) return false;
+    if ((W & 1) || (pad & 1)) return false;                                    // 8-byte aligned column pairs
+    const int outH = H + 2 * pad - 2, outW = W + 2 * pad - 2;
+    if (outH <= 0 || outW <= 0) return false;
+    const long long pitch = outRowStride > 0 ? outRowStride : outW;
+    if ((pitch & 1) != 0) return false;
+    // every store offset a lane can form (padded channels included) stays below 2^31
+    if ((long long)(ceil_div(O, 64) * 64 + 32) * outH * pitch * 4 >= 0x7fffffffLL) return false;
+    if ((long long)I * H * W * 4 >= 0x7fffffffLL) return false;
+    if ((long long)ceil_div(O, 64) * ceil_div(I, 16) * 49152 >= 0x7fffffffLL) return false;
+    return true;
+}
+
+template <int TN>
+static int launch_f23(const sg3_modconv_params& q, hipStream_t st) {
+    constexpr size_t ldsBytes = (size_t)2 * 16 * (2 * TN + 2) * 256;
+    static_assert(ldsBytes >= 65536 && ldsBytes <= 160 * 1024, "LDS: double-buffered B image, at least the 64 KB exchange area");
+    F23Params p;
+    p.x = (const float*)q.x; p.wp = q.wPacked; p.sIn = q.sIn; p.dcoef = q.dcoef; p.out = (float*)q.out;
+    p.N = q.N; p.I = q.I; p.O = q.O; p.H = q.H; p.W = q.W; p.pad = q.pad;
+    p.outH = q.H + 2 * q.pad - 2; p.outW = q.W + 2 * q.pad - 2;
+    p.nch = ceil_div(q.I, 16);
+    p.xTiles = ceil_div(p.outW, 32); p.yTiles = ceil_div(p.outH, 2 * TN); p.mTiles = ceil_div(q.O, 64);
+    const long long total = (long long)p.xTiles * p.yTiles * p.mTiles * q.N;
+    if (total > 0x7fffffffLL) { set_error("modulated_conv2d: grid too large"); return SG3_BAD_ARG; }
+    p.totalBlocks = (int)total;
+    p.outPitch = q.outRowStride > 0 ? q.outRowStride : p.outW;
+#ifdef SG3_F23_STAMPS
+    p.stamps = g_f23_stamps;
+#endif
+    auto kern = modconv_f23_kernel<TN>;
+    SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), ldsBytes, st, p);
+    SG3_LAUNCH_CHECK("modconv_f23_kernel");
+    return SG3_OK;
+}
+
+int launch_conv_f23(const sg3_modconv_params& q, hipStream_t st) {
+    // rows per wave: one workgroup per CU, so the time goes with (rounds of 256 workgroups) x (rows per wave + per-chunk overhead)
+    const char* fe = getenv("SG3_F23_TN");                 // A/B timing and tests: 4 | 5 | 7 rows per wave (read per call)
+    const int forced = fe ? atoi(fe) : 0;
+    const int outH = q.H + 2 * q.pad - 2, outW = q.W + 2 * q.pad - 2;
+    const long long per = (long long)q.N * ceil_div(q.O, 64) * ceil_div(outW, 32);
+    int best = 7; double bestCost = 1e300;
+    const int cands[3] = {7, 5, 4};
+    for (int c = 0; c < 3; c++) {
+        const int tn = cands[c];
+        const long long wgs = per * ceil_div(outH, 2 * tn);
+        const double rounds = wgs <= 1024 ? (double)ceil_div64(wgs, 256) : wgs / 256.0;
+        const double cost = rounds * (tn + 0.6);
+        if (cost < bestCost * 0.999) { bestCost = cost; best = tn; }
+    }
+    if (forced == 4 || forced == 5 || forced == 7) best = forced;
+    switch (best) {
+        case 4: return launch_f23<4>(q, st);
+        case 5: return launch_f23<5>(q, st);
+        default: return launch_f23<7>(q, st);
+    }
+}
+
+} // namespace sg3

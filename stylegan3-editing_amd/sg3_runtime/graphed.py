@@ -8,9 +8,11 @@ is copied in, the image comes out of a static tensor that is overwritten by the 
 
 What a captured graph bakes in, and how a replay stays valid:
   * device pointers of every tensor it reads.  `synthesis.input.transform` is REBOUND by the callers (pSp.forward,
-    PTI, the FOV expander assign a fresh tensor per call), so the graph owns a static [batch,3,3] transform buffer, installs
-    it on the module for the capture and, on every replay, copies whatever transform the module (or the `transform=`
-    argument) currently holds into it and re-installs it;
+    PTI, the FOV expander assign a fresh tensor per call), so the graph owns a static [batch,3,3] transform buffer.  That
+    buffer shadows the module attribute ONLY while the graph is warmed up and captured; afterwards the caller's own tensor is
+    back on the module (eager calls with another batch size, `state_dict()` and `load_state_dict` see the user's [3,3] or
+    [B,3,3] transform), and every replay copies whatever transform the module (or the `transform=` argument) holds then into
+    the static buffer;
   * host-side values derived from parameters (activation bounds inside the convolution launch parameters, the
     magnitude_ema gains of eager-mode prep).  Parameters and buffers are fingerprinted at capture (data_ptr, _version); a
     replay after any of them changed raises instead of returning an image of the old weights: re-capture after tuning.
@@ -45,36 +47,46 @@ class GraphedSynthesis:
             self.static_ws = torch.zeros([batch, generator.num_ws, generator.w_dim], device=dev)
         self.batch = int(batch)
         self.static_transform = torch.eye(3, device=dev).repeat(self.batch, 1, 1)
-        self._install_transform(generator.synthesis.input.transform)
-        # warm up on a side stream (lazy inits, bound caches, allocator), then capture
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):
-                self._eager()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        # thread-local capture: other threads of the process (e.g. the RCCL watchdog of torch.distributed, which polls
-        # events) may keep calling into the runtime while this thread captures
-        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-            self.static_out = self._eager()
+        inp = generator.synthesis.input
+        user_transform = inp.transform
+        self._load_transform(user_transform)
+        inp.transform = self.static_transform                 # shadows the user's tensor during warm-up and capture only
+        try:
+            # warm up on a side stream (lazy inits, bound caches, allocator), then capture
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(warmup):
+                    self._eager()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            # thread-local capture: other threads of the process (e.g. the RCCL watchdog of torch.distributed, which polls
+            # events) may keep calling into the runtime while this thread captures
+            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+                self.static_out = self._eager()
+        finally:
+            inp.transform = user_transform
         self._fingerprint = self._weights_fingerprint()
         self._pinned = _cached_inference_tensors(self.G.synthesis)
 
-    def _install_transform(self, t):
-        """Copy `t` ([3,3] or [batch,3,3]) into the graph's transform buffer and make that buffer the module's transform."""
-        if t is not self.static_transform:
-            t = torch.as_tensor(t, device=self.device, dtype=torch.float32)
-            if t.dim() == 3 and t.shape[0] not in (1, self.batch):
-                raise ValueError(f'transform batch {t.shape[0]} does not match the captured batch {self.batch}')
-            self.static_transform.copy_(t.expand(self.batch, 3, 3) if t.dim() == 3 else t.unsqueeze(0).expand(self.batch, 3, 3))
-        self.G.synthesis.input.transform = self.static_transform
+    def _load_transform(self, t):
+        """Copy `t` ([3,3], [1,3,3] or [batch,3,3]) into the graph's transform buffer (the module keeps the caller's tensor)."""
+        if t is self.static_transform:
+            return
+        t = torch.as_tensor(t, device=self.device, dtype=torch.float32)
+        if t.dim() == 3 and t.shape[0] not in (1, self.batch):
+            raise ValueError(f'transform batch {t.shape[0]} does not match the captured batch {self.batch}')
+        self.static_transform.copy_(t.expand(self.batch, 3, 3) if t.dim() == 3 else t.unsqueeze(0).expand(self.batch, 3, 3))
 
     def _weights_fingerprint(self):
         inp = self.G.synthesis.input
         return tuple((t.data_ptr(), t._version) for t in list(self.G.synthesis.parameters()) + list(self.G.synthesis.buffers())
                      if t is not self.static_transform and t is not inp.transform)
+
+    def is_stale(self):
+        """True when a parameter or buffer of the synthesis network changed (or was replaced) since the capture."""
+        return self._weights_fingerprint() != self._fingerprint
 
     def _eager(self):
         if self.use_s:
@@ -83,10 +95,10 @@ class GraphedSynthesis:
 
     def __call__(self, ws=None, all_s=None, transform=None):
         """Copy the inputs (and the current user transform) into the graph's static buffers, replay, return the static output."""
-        if self._weights_fingerprint() != self._fingerprint:
+        if self.is_stale():
             raise RuntimeError('GraphedSynthesis: generator parameters / buffers changed since capture (the graph holds their old '
-                               'pointers and values derived from them); build a new GraphedSynthesis')
-        self._install_transform(self.G.synthesis.input.transform if transform is None else transform)
+                               'pointers and values derived from them); build a new GraphedSynthesis (is_stale() tells beforehand)')
+        self._load_transform(self.G.synthesis.input.transform if transform is None else transform)
         if self.use_s:
             for k, v in all_s.items():
                 self.static_s[k].copy_(v, non_blocking=True)
@@ -118,16 +130,20 @@ class GraphedReStyleStep:
         self.prev_image = torch.zeros([self.batch, 3, 256, 256], device=dev)
         self.prev_latent = torch.zeros([self.batch, int(net.n_styles), int(G.w_dim)], device=dev)
         self.identity = torch.eye(3, device=dev).repeat(self.batch, 1, 1)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):
-                self._eager()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-            self.image, self.latent, self.pooled = self._eager()
+        user_transform = G.synthesis.input.transform          # the graph's identity shadows it during warm-up and capture only
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(warmup):
+                    self._eager()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+                self.image, self.latent, self.pooled = self._eager()
+        finally:
+            G.synthesis.input.transform = user_transform
         self._fingerprint = self._weights_fingerprint()
         self._pinned = _cached_inference_tensors(self.net.decoder.synthesis)
 
@@ -135,6 +151,10 @@ class GraphedReStyleStep:
         G = self.net.decoder
         tensors = list(self.net.encoder.parameters()) + list(self.net.encoder.buffers()) + list(G.synthesis.parameters()) + list(G.synthesis.buffers())
         return tuple((t.data_ptr(), t._version) for t in tensors if t is not self.identity and t is not G.synthesis.input.transform)
+
+    def is_stale(self):
+        """True when an encoder / generator parameter or buffer changed (or was replaced) since the capture."""
+        return self._weights_fingerprint() != self._fingerprint
 
     def _eager(self):
         net = self.net
@@ -145,11 +165,11 @@ class GraphedReStyleStep:
 
     def __call__(self, frames, prev_image, prev_latent):
         """Returns (image [B,3,R,R], latent [B,n_styles,512], image pooled to 256^2): static tensors, overwritten by the next replay."""
-        if self._weights_fingerprint() != self._fingerprint:
-            raise RuntimeError('GraphedReStyleStep: encoder / generator weights changed since capture; build a new one')
+        if self.is_stale():
+            raise RuntimeError('GraphedReStyleStep: encoder / generator weights changed since capture; build a new one '
+                               '(is_stale() tells beforehand; run_on_batch falls back to the eager loop)')
         self.frames.copy_(frames, non_blocking=True)
         self.prev_image.copy_(prev_image, non_blocking=True)
         self.prev_latent.copy_(prev_latent.expand_as(self.prev_latent), non_blocking=True)
-        self.net.decoder.synthesis.input.transform = self.identity
-        self.graph.replay()
+        self.graph.replay()                                   # reads the graph's own identity buffer: the module's transform is not touched
         return self.image, self.latent, self.pooled

@@ -9,7 +9,6 @@ per-sample modulation), so rank r takes the contiguous range [start_r, stop_r) a
 all-gather of [frames_r, 16, 512] fp32 (1 MiB per rank for 256 frames on 8 GPUs) plus the optional [frames_r, 3, 3]
 transforms: latency-bound, one call per video.  Weights are replicated (encoder 186 M + generator 22 M parameters).
 """
-import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -68,7 +67,7 @@ class ShardedInversion:
         if use_graph and device.type == 'cuda' and not getattr(opts, 'resize_outputs', False):
             from .graphed import GraphedReStyleStep
             have = getattr(net, 'graphed_step', None)
-            if have is None or have.batch != self.batch_size:
+            if have is None or have.batch != self.batch_size or have.is_stale():      # stale: weights changed since that capture
                 try:
                     net.graphed_step = GraphedReStyleStep(net, self.batch_size)
                 except RuntimeError as err:                      # capture refused: the eager loop is always there
@@ -80,17 +79,37 @@ class ShardedInversion:
         its own range.  Returns (latents [F,16,512] of the last ReStyle step, identical on every rank; this rank's
         frame range)."""
         from utils.inference_utils import run_on_batch
+        from torch_utils.ops import plain_conv
         n = int(frames.shape[0])
         start, stop = shard_range(n, self.rank, self.world)
         device = next(self.net.parameters()).device
-        local = []
+
+        def batch(b0, b1, check_range):
+            x = frames[b0:b1].to(device, non_blocking=True).float()
+            lt = None if landmarks_transforms is None else landmarks_transforms[b0:b1].to(device).float()
+            return run_on_batch(x, self.net, self.opts, self.avg_image, landmarks_transform=lt, final_latents_only=True, check_range=check_range)
+
+        # The latents stay on the device from the encoder to the all-gather.  Graph-replayed (full) batches cannot read the encoder's
+        # split-precision range flag per batch without a host sync: it is reset once here and read once after the last full batch; if
+        # any of them raised it (operands beyond the fp16 range), they are repeated on the eager path, which owns the fp32 form.
+        # A ragged last batch runs eagerly (its encoder forward resets and reads the flag itself), after that read.
+        bounds = [(b0, min(b0 + self.batch_size, stop)) for b0 in range(start, stop, self.batch_size)]
         with torch.no_grad():
-            for b0 in range(start, stop, self.batch_size):
-                b1 = min(b0 + self.batch_size, stop)
-                x = frames[b0:b1].to(device, non_blocking=True).float()
-                lt = None if landmarks_transforms is None else landmarks_transforms[b0:b1].to(device).float()
-                _, lats = run_on_batch(x, self.net, self.opts, self.avg_image, landmarks_transform=lt)
-                local.append(torch.from_numpy(np.stack([lats[i][-1] for i in range(b1 - b0)])).to(device))
+            graphed = device.type == 'cuda' and getattr(self.net, 'graphed_step', None) is not None and not self.net.graphed_step.is_stale()
+            full = [bd for bd in bounds if graphed and bd[1] - bd[0] == self.batch_size]
+            if full:
+                plain_conv.reset_overflow(device)
+            local = {bd: batch(*bd, check_range=False) for bd in full}
+            if full and plain_conv.overflowed(device):
+                keep, self.net.graphed_step = self.net.graphed_step, None
+                try:
+                    local = {bd: batch(*bd, check_range=True) for bd in full}
+                finally:
+                    self.net.graphed_step = keep
+            for bd in bounds:
+                if bd not in local:
+                    local[bd] = batch(*bd, check_range=True)
+            local = [local[bd] for bd in bounds]
         width = (int(self.net.n_styles), int(self.net.latent_avg.shape[-1]))
         local = torch.cat(local, dim=0) if local else torch.zeros([0, *width], device=device)
         return all_gather_ragged(local, n), (start, stop)

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_PKG_ROOT, 'lib', 'libsg3hip.so')
 
 SG3_OK, SG3_NO_KERNEL, SG3_BAD_ARG, SG3_HIP_ERROR = 0, -1, -2, -3
 SG3_F32, SG3_F16, SG3_F64 = 0, 1, 2
-SG3_CONV_FP32, SG3_CONV_F16X3, SG3_CONV_F16 = 0, 1, 2
+SG3_CONV_FP32, SG3_CONV_F16X3, SG3_CONV_F16, SG3_CONV_F16X3_F23 = 0, 1, 2, 3
 _DTYPE = {torch.float32: SG3_F32, torch.float16: SG3_F16, torch.float64: SG3_F64}
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
@@ -116,6 +116,7 @@ EXPORTS = [
     ('sg3_bias_act', ctypes.c_int, [ctypes.POINTER(BiasActParams), c_vp]),
     ('sg3_modconv_packed_floats', ctypes.c_int64, [ctypes.c_int] * 4),
     ('sg3_modulated_conv2d', ctypes.c_int, [ctypes.POINTER(ModconvParams), c_vp]),
+    ('sg3_modconv_f23_supported', ctypes.c_int, [ctypes.c_int] * 8),
     ('sg3_fourier_features', ctypes.c_int, [ctypes.POINTER(FourierParams), c_vp]),
     ('sg3_input_transform', ctypes.c_int, [ctypes.POINTER(InputTransformParams), c_vp]),
     ('sg3_affine_batch', ctypes.c_int, [ctypes.POINTER(AffineBatchParams), c_vp]),

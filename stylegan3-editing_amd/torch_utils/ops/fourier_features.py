@@ -36,6 +36,8 @@ def input_transform(t, user, freqs, phases, bandwidth, sampling_rate, normalise)
     if not (t.is_cuda and t.dtype == user.dtype == freqs.dtype == phases.dtype == torch.float32):
         raise RuntimeError('input_transform: float32 CUDA tensors expected')
     n, c = int(t.shape[0]), int(freqs.shape[0])
+    if user.ndim == 3 and user.shape[0] == 1:
+        user = user[0]                                      # a [1,3,3] transform broadcasts over the batch, as in the reference's matmul
     if tuple(t.shape) != (n, 4) or tuple(freqs.shape) != (c, 2) or tuple(phases.shape) != (c,) or tuple(user.shape) not in ((3, 3), (n, 3, 3)):
         raise RuntimeError(f'input_transform: shapes {tuple(t.shape)}, {tuple(user.shape)}, {tuple(freqs.shape)}, {tuple(phases.shape)}')
     lib = abi.load()

@@ -32,6 +32,10 @@ from .. import misc
 # Calls without a bound always use 'fp32'.  fp16 tensors (the reference's mixed-precision layers) take the plain fp16
 # form: operands rounded to fp16 once, one MFMA per K step, fp32 accumulation -- what an fp16 cuDNN convolution does.
 precision = 'f16x3'
+# Transform-domain form of the split-precision 3x3 kernel (SG3_CONV_F16X3_F23, csrc/sg3_modconv_f23.hip: Winograd F(2,3) along x,
+# two thirds of the matrix instructions).  'auto': layers whose channel counts fill its 64-channel x 16-channel tiles;
+# 'on': every call the kernel supports; 'off': never.  SG3_CONV_F23 in the environment sets the initial value.
+f23 = {'0': 'off', '1': 'on'}.get(os.environ.get('SG3_CONV_F23', ''), 'auto')
 # `align_rows` requests are honoured unless SG3_CONV_DENSE_ROWS=1 (A/B timing of the padded row pitch)
 _ALIGN_ROWS = os.environ.get('SG3_CONV_DENSE_ROWS', '0') != '1'
 
@@ -67,6 +71,15 @@ def _effective_weights(w, s, demodulate, input_gain, n):
     return w
 
 
+def _f23_wanted(ci, co, h, wd, padding):
+    """Heuristic of `f23 = 'auto'`: the transform-domain kernel works on 64 output channels x 16 input channels x 32 columns;
+    thin layers (few K chunks per tile, HBM-bound) and narrow planes stay on the direct kernel."""
+    if f23 == 'on':
+        return True
+    ow = wd + 2 * padding - 2
+    return ci >= 128 and co >= 96 and ow >= 64
+
+
 class _Prepared:
     """What the prep kernels produce for one (w, s) pair -- packed normalised weights, per-sample input scales and
     demodulation coefficients -- plus the settings the convolution launch must repeat."""
@@ -76,7 +89,8 @@ class _Prepared:
 # Inference keeps the packed (normalised, split, tile-ordered) weights and their per-(o, i) energies of a layer between calls:
 # they depend on the weight tensor alone, and packing all layers' weights is 80 us of a 21 ms T-1024 step.  An entry is valid for
 # the tensor object it was made from at the `(data_ptr, _version)` it was made at -- optimiser steps, `copy_`, `load_state_dict`
-# all bump the version; writes through `.data` do not, and need `clear_weight_cache()`.
+# all bump the version; writes through `.data` do not, and need `clear_weight_cache()`.  An entry is dropped when its weight
+# tensor is collected (weakref.finalize), so deleted generators do not leave their packed weights resident.
 _packed_weights = {}          # id(weight) -> (weakref to the weight, key, wn, wsq)
 
 
@@ -125,6 +139,9 @@ def _plan(w, s, demodulate, padding, input_gain, x_bound, x_bound_dev, n, h, wd,
     # 1x1: ToRGB (O <= 4) is HBM-bound and has its own kernel; the GEMM kernel loads pixel pairs (even plane size)
     split = precision == 'f16x3' and (k == 3 or (padding == 0 and co > 4 and (h * wd) % 2 == 0)) and bounded
     prec = (abi.SG3_CONV_F16 if dtype == torch.float16 else abi.SG3_CONV_F16X3) if split else abi.SG3_CONV_FP32
+    if prec == abi.SG3_CONV_F16X3 and k == 3 and f23 != 'off' and _f23_wanted(ci, co, h, wd, int(padding)) \
+            and lib.sg3_modconv_f23_supported(abi.SG3_F32, ci, co, h, wd, k, int(padding), 0):
+        prec = abi.SG3_CONV_F16X3_F23
     pr = _Prepared()
     pr.prec = prec
     pr.key = (n, ci, co, k, h, wd, int(padding), dtype)
@@ -136,9 +153,9 @@ def _plan(w, s, demodulate, padding, input_gain, x_bound, x_bound_dev, n, h, wd,
         pr.wn = torch.empty([int(lib.sg3_modconv_packed_floats(co, ci, k, prec))], dtype=torch.float32, device=dev)
         pr.wsq = torch.empty([co, ci], dtype=torch.float32, device=dev)
         if reuse_weights:
-            if len(_packed_weights) > 256:            # entries of dead tensors
-                for key in [k_ for k_, v in _packed_weights.items() if v[0]() is None]:
-                    del _packed_weights[key]
+            if id(w) not in _packed_weights:
+                # the entry (and with it the packed copies on the GPU) goes when the weight tensor does
+                weakref.finalize(w, _packed_weights.pop, id(w), None)
             _packed_weights[id(w)] = (weakref.ref(w), wkey, pr.wn, pr.wsq)
     pr.s_in = torch.empty([n, ci], dtype=torch.float32, device=dev)
     pr.dcoef = torch.empty([n, co], dtype=torch.float32, device=dev) if (demodulate or split) else None

@@ -1,0 +1,122 @@
+"""Transform-domain 3x3 modulated convolution (SG3_CONV_F16X3_F23, csrc/sg3_modconv_f23.hip: Winograd F(2,3) along x on the
+split-precision matrix-core arithmetic) against the fp64 oracle and against the direct split-precision kernel.
+Reference semantics: models/stylegan3/networks_stylegan3.py:24-63.
+
+Tolerance: relative max error vs fp64 <= 5e-6 -- the bound test_gpu_ops.py holds the direct f16x3 and exact-fp32 kernels to."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_cases import rand
+from helpers import maxabs
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+class _f23:
+    def __init__(self, mode, tn=None):
+        self.mode, self.tn = mode, tn
+
+    def __enter__(self):
+        from torch_utils.ops import modulated_conv as mc
+        self.prev, self.prev_tn = mc.f23, os.environ.get('SG3_F23_TN')
+        mc.f23 = self.mode
+        if self.tn is not None:
+            os.environ['SG3_F23_TN'] = str(self.tn)
+        return mc
+
+    def __exit__(self, *exc):
+        from torch_utils.ops import modulated_conv as mc
+        mc.f23 = self.prev
+        if self.prev_tn is None:
+            os.environ.pop('SG3_F23_TN', None)
+        else:
+            os.environ['SG3_F23_TN'] = self.prev_tn
+
+
+def _took_f23(mc, x, w, pad):
+    from torch_utils import _sg3abi as abi
+    n, ci, h, wd = x.shape
+    return bool(abi.load().sg3_modconv_f23_supported(abi.SG3_F32, ci, int(w.shape[0]), h, wd, 3, pad, 0))
+
+
+@pytest.mark.parametrize('tn', [4, 5, 7])
+@pytest.mark.parametrize('n,ci,co,h,w,pad', [
+    (2, 64, 64, 30, 30, 2),            # one M tile, one column tile
+    (1, 323, 203, 22, 26, 2),          # odd channel counts: padded K chunk, an M block of pure padding
+    (2, 81, 51, 40, 70, 2),            # O < 64: second M block inactive; three column tiles with a ragged last one
+    (1, 512, 512, 20, 36, 2),          # 32 chunks
+    (3, 17, 130, 35, 34, 0),           # pad 0 (the data-gradient form), two K chunks, rows ragged for every TN
+    (1, 16, 96, 9, 10, 2),             # one chunk (no prefetch), tiny plane
+])
+def test_f23_matches_fp64_and_direct_kernel(n, ci, co, h, w, pad, tn):
+    from oracle import oracle as O
+    x = np.clip(rand(71, n, ci, h, w) * 40, -256, 256).astype(np.float32); wt = rand(72, co, ci, 3, 3); s = rand(73, n, ci) + 1
+    ref = O.modulated_conv2d(x.astype(np.float64), wt.astype(np.float64), s.astype(np.float64), True, pad, 0.8)
+    scale = max(1.0, float(np.abs(ref).max()))
+    kw = dict(demodulate=True, padding=pad, input_gain=torch.tensor(0.8, device=DEV), x_bound=256.0)
+    with _f23('on', tn) as mc:
+        assert _took_f23(mc, x, wt, pad)
+        y = mc.modulated_conv2d(T(x), T(wt), T(s), **kw)
+    with _f23('off') as mc:
+        yd = mc.modulated_conv2d(T(x), T(wt), T(s), **kw)
+    assert tuple(y.shape) == ref.shape
+    e23, ed = maxabs(y.cpu().numpy(), ref) / scale, maxabs(yd.cpu().numpy(), ref) / scale
+    print(f'relative max error vs fp64: transform domain {e23:.2e}, direct {ed:.2e}')
+    assert e23 <= 5e-6, (e23, ed)
+    # large styles: the per-sample power-of-two rescale leaves one more bit of headroom for the transformed samples
+    s_big = (s * 1000).astype(np.float32)
+    with _f23('on', tn) as mc:
+        y2 = mc.modulated_conv2d(T(x), T(wt), T(s_big), demodulate=False, padding=pad, input_gain=None, x_bound=256.0)
+    ref2 = O.modulated_conv2d(x.astype(np.float64), wt.astype(np.float64), s_big.astype(np.float64), False, pad, None)
+    assert bool(torch.isfinite(y2).all())
+    assert maxabs(y2.cpu().numpy(), ref2) <= 5e-6 * float(np.abs(ref2).max())
+
+
+def test_f23_saturated_input_stays_in_range():
+    """Every sample at the bound with alternating signs: the transformed operands reach 2 x bound."""
+    from oracle import oracle as O
+    n, ci, co, h, w = 1, 32, 64, 12, 40
+    x = np.full([n, ci, h, w], 256.0, dtype=np.float32); x[..., ::2] *= -1; x[:, ::3] *= -1
+    wt = rand(5, co, ci, 3, 3); s = np.abs(rand(6, n, ci)) + 0.5
+    with _f23('on') as mc:
+        y = mc.modulated_conv2d(T(x), T(wt), T(s), demodulate=True, padding=2, x_bound=256.0)
+    ref = O.modulated_conv2d(x.astype(np.float64), wt.astype(np.float64), s.astype(np.float64), True, 2, None)
+    assert bool(torch.isfinite(y).all())
+    assert maxabs(y.cpu().numpy(), ref) <= 5e-6 * float(np.abs(ref).max())
+
+
+@pytest.mark.parametrize('n,ci,co,h', [(2, 64, 70, 150), (1, 128, 96, 278)])
+def test_f23_aligned_row_pitch_and_batch_independence(n, ci, co, h):
+    x = T(rand(41, n, ci, h, h)); w = T(rand(42, co, ci, 3, 3)); s = T(rand(43, n, ci) + 1.5)
+    with _f23('on') as mc, torch.no_grad():
+        dense = mc.modulated_conv2d(x, w, s, demodulate=True, padding=2, x_bound=8.0)
+        view = mc.modulated_conv2d(x, w, s, demodulate=True, padding=2, x_bound=8.0, align_rows=True)
+        assert view.stride(2) % 32 == 0 and torch.equal(view, dense)
+        one = mc.modulated_conv2d(x[:1], w, s[:1], demodulate=False, padding=2, x_bound=8.0)
+        both = mc.modulated_conv2d(x, w, s, demodulate=False, padding=2, x_bound=8.0)
+        assert torch.equal(one[0], both[0])
+
+
+def test_f23_unsupported_shapes_fall_back():
+    """Odd widths / odd padding / fp16 tensors are refused by the query and run on the direct kernel."""
+    from torch_utils import _sg3abi as abi
+    lib = abi.load()
+    assert lib.sg3_modconv_f23_supported(abi.SG3_F32, 64, 64, 30, 31, 3, 2, 0) == 0
+    assert lib.sg3_modconv_f23_supported(abi.SG3_F32, 64, 64, 30, 30, 3, 1, 0) == 0
+    assert lib.sg3_modconv_f23_supported(abi.SG3_F16, 64, 64, 30, 30, 3, 2, 0) == 0
+    assert lib.sg3_modconv_f23_supported(abi.SG3_F32, 64, 64, 30, 30, 1, 0, 0) == 0
+    assert lib.sg3_modconv_f23_supported(abi.SG3_F32, 64, 64, 30, 30, 3, 2, 0) == 1
+    from oracle import oracle as O
+    x = rand(1, 1, 64, 20, 31); w = rand(2, 64, 64, 3, 3); s = rand(3, 1, 64) + 1
+    with _f23('on') as mc:
+        y = mc.modulated_conv2d(T(x), T(w), T(s), demodulate=True, padding=2, x_bound=8.0)
+    ref = O.modulated_conv2d(x, w, s, True, 2, None)
+    assert maxabs(y.cpu().numpy(), ref) <= 3e-5 * max(1.0, float(np.abs(ref).max()))

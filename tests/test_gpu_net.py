@@ -282,6 +282,28 @@ def test_torgb_epilogue_fused_and_refused():
             mc.modulated_conv2d(x, w3, s, padding=2, epilogue=(torch.zeros(8, device=DEV), 40.0, 1.0))
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_torgb_epilogue_keeps_nan(dtype):
+    """the fused ToRGB output stage must let a NaN through its clamp, as the reference's filtered_lrelu does
+    (filtered_lrelu.cu:412-419): checked against the CPU composite (torch_utils ref path), NaN positions and finite values."""
+    from torch_utils.ops import filtered_lrelu as fl
+    from torch_utils.ops import modulated_conv as mc
+    g = torch.Generator(device=DEV).manual_seed(12)
+    x = (torch.randn([1, 16, 32, 32], device=DEV, generator=g) * 30).to(dtype)
+    x[0, 3, 5, 7] = float('nan'); x[0, 0, 20, 1] = float('nan')
+    w = torch.randn([3, 16, 1, 1], device=DEV, generator=g)
+    s = torch.randn([1, 16], device=DEV, generator=g) + 1
+    b = torch.randn([3], device=DEV, generator=g)
+    with torch.no_grad():
+        got = mc.modulated_conv2d(x, w, s, demodulate=False, padding=0, epilogue=(b, 20.0, 0.5))
+        plain = mc._composite(x.float().cpu(), w.cpu(), s.cpu(), False, 0, None)
+        want = fl.filtered_lrelu(plain, b=b.cpu(), up=1, down=1, padding=0, gain=1, slope=1, clamp=20.0, impl='ref') * 0.5
+    got = got.float().cpu()
+    nan = torch.isnan(want)
+    assert int(nan.sum()) == 6 and torch.equal(torch.isnan(got), nan)           # two pixels x three output channels
+    assert maxabs(got[~nan].numpy(), want[~nan].numpy()) <= (2e-5 if dtype == torch.float32 else 2e-2) * 20
+
+
 def test_t1024_batch8_headline_workload():
     """BASELINE configs[1] exactly as bench.py runs it (batch 8, force_fp32): sample 0 against the reference's golden samples /
     statistics, sample 7 against its own batch-1 forward, eagerly and through the captured hipGraph."""
@@ -327,6 +349,47 @@ def test_graph_replay_follows_transform_rebinding_and_refuses_stale_weights():
         G.synthesis.L3_36_12.bias.add_(0.5)                    # tuning step
     with pytest.raises(RuntimeError, match='changed since capture'):
         graphed(ws)
+
+
+def test_graph_leaves_the_users_transform_on_the_module():
+    """the graph's static [batch,3,3] transform buffer shadows `synthesis.input.transform` only during capture.  Afterwards
+    the module carries the caller's tensor again: eager calls at another batch size work, `state_dict()` holds a loadable [3,3]
+    transform, and a [1,3,3] transform broadcasts over the batch eagerly and through the graph alike."""
+    from sg3_runtime import GraphedSynthesis
+    G = build_product_generator('Ttiny', device=DEV)
+    user = T(make_user_transform((0.1, -0.05), 15.0))
+    G.synthesis.input.transform = user
+    graphed = GraphedSynthesis(G, 2)
+    assert G.synthesis.input.transform is user
+    assert tuple(G.state_dict()['synthesis.input.transform'].shape) == (3, 3)
+    build_product_generator('Ttiny').load_state_dict(G.state_dict())            # loads into a fresh generator
+    ws3 = T(synth_ws(3, G.num_ws, G.w_dim, seed=2))
+    with torch.no_grad():
+        img3 = G.synthesis(ws3, noise_mode='const', force_fp32=True)            # another batch size, eager
+        assert tuple(img3.shape)[0] == 3
+        got = graphed(ws3[:2]).clone()
+        assert G.synthesis.input.transform is user
+        assert maxabs(got.cpu().numpy(), img3[:2].cpu().numpy()) <= 1e-6
+        # [1,3,3]: broadcast over the batch (reference: rot @ trans @ self.transform)
+        G.synthesis.input.transform = user.unsqueeze(0)
+        one = G.synthesis(ws3, noise_mode='const', force_fp32=True)
+        assert maxabs(one.cpu().numpy(), img3.cpu().numpy()) <= 1e-6
+        assert maxabs(graphed(ws3[:2]).cpu().numpy(), img3[:2].cpu().numpy()) <= 1e-6
+
+
+def test_packed_weight_cache_follows_the_weights_lifetime():
+    """the inference cache of packed convolution weights drops an entry when its weight tensor is collected."""
+    import gc
+    from torch_utils.ops import modulated_conv as mc
+    mc.clear_weight_cache()
+    G = build_product_generator('Ttiny', device=DEV)
+    ws = T(synth_ws(1, G.num_ws, G.w_dim, seed=1))
+    with torch.no_grad():
+        G.synthesis(ws, noise_mode='const', force_fp32=True)
+    assert len(mc._packed_weights) > 0
+    del G
+    gc.collect()
+    assert len(mc._packed_weights) == 0
 
 
 def test_graph_replay_survives_cache_turnover():

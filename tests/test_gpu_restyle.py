@@ -144,3 +144,105 @@ def test_run_on_batch_with_resnet34_encoder_matches_oracle():
         got_l = np.stack([lats[i][it] for i in range(2)])
         assert maxabs(got_l, lats_o[it]) <= 2e-4 * max(1.0, float(np.abs(lats_o[it]).max())), it
         assert maxabs(torch.stack([imgs[i][it] for i in range(2)]).cpu().numpy(), imgs_o[it]) <= 1e-4, it
+
+
+@pytest.mark.parametrize('stage', [99, 5])
+def test_e4e_forward_and_restyle_loop_match_oracle(stage):
+    """`e4e(opts, decoder=G)` with the ProgressiveBackboneEncoder on the HIP path (reference models/setgan/encoder/e4e3.py:45-87,
+    encoders/restyle_e4e_encoders.py:79-89): e4e.forward (first step on latent_avg, residual step, landmark transforms, pooling)
+    and a 3-step run_on_batch against the oracle loop driven by the progressive combination w[:, i] = w0 + delta_i (i <= stage)
+    of the oracle's IR-SE50 heads."""
+    import types
+    from models.setgan.encoder.e4e3 import e4e
+    from oracle import oracle as O
+    from synth_weights import synth_encoder_state_dict
+    from torch_utils import _sg3abi
+    from utils.inference_utils import get_average_image, run_on_batch
+    from helpers import build_oracle_generator
+    G = build_product_generator('Rmini')
+    opts = types.SimpleNamespace(encoder_type='ProgressiveBackboneEncoder', input_nc=6, n_styles=int(G.num_ws), checkpoint_path=None,
+                                 n_iters_per_batch=3, resize_outputs=False, sgxl=False)
+    net = e4e(opts, decoder=G)
+    assert type(net.encoder).__name__ == 'ProgressiveBackboneEncoder' and type(net).forward is type(net).__mro__[1].forward
+    man = {k: list(v.shape) for k, v in net.encoder.state_dict().items()}
+    enc_sd = {k: np.asarray(v) for k, v in synth_encoder_state_dict(man, seed=0).items()}
+    net.encoder.load_state_dict({k: torch.from_numpy(v) for k, v in enc_sd.items()})
+    net.encoder.progressive_stage = stage
+    net = net.eval().requires_grad_(False).to(DEV)
+    gen_sd, sched = build_oracle_generator('Rmini')
+    lat_avg = gen_sd['mapping.w_avg']
+    n_styles = int(G.num_ws)
+
+    def enc(x6):                                                            # restyle_e4e_encoders.py:79-89
+        per = O.backbone_encoder(enc_sd, x6, n_styles=n_styles)
+        w = np.repeat(per[:, :1], n_styles, axis=1).copy()
+        for i in range(1, min(stage + 1, n_styles)):
+            w[:, i] += per[:, i]
+        return w
+
+    x, lt = _frames(2, seed=9), _landmarks(2)
+    avg_o = O.get_average_image(None, gen_sd, sched, lat_avg)
+    imgs_o, lats_o, aligned_last_o = O.run_on_batch(None, gen_sd, sched, x, lat_avg, avg_o, 3, landmarks_transform=lt, encoder=enc)
+    n0 = _sg3abi.launch_count
+    with torch.no_grad():
+        avg = get_average_image(net)
+        assert maxabs(avg.cpu().numpy(), avg_o) <= 1e-5
+        xt, ltt = torch.from_numpy(x).to(DEV), torch.from_numpy(lt).to(DEV)
+        # e4e.forward itself: first step (6 channels, no latent) and a residual step, all three return forms
+        x6 = torch.cat([xt, avg.unsqueeze(0).repeat(2, 1, 1, 1)], dim=1)
+        first = net.forward(x6, latent=None, resize=True, return_latents=True)
+        want0 = enc(x6.cpu().numpy()) + lat_avg.reshape(1, 1, -1)
+        assert tuple(first[0].shape) == (2, 3, 256, 256)
+        assert maxabs(first[1].cpu().numpy(), want0) <= 2e-4 * float(np.abs(want0).max())
+        al, un, codes = net.forward(x6, latent=first[1], landmarks_transform=ltt, return_aligned_and_unaligned=True, return_latents=True, resize=False)
+        want1 = enc(x6.cpu().numpy()) + first[1].cpu().numpy()
+        assert maxabs(codes.cpu().numpy(), want1) <= 2e-4 * float(np.abs(want1).max())
+        assert al.shape == un.shape and maxabs(al.cpu().numpy(), un.cpu().numpy()) > 1e-3          # the transforms move the image
+        only = net.forward(first[1], input_code=True, resize=False)
+        assert torch.is_tensor(only) and maxabs(only.cpu().numpy(), O.psp_forward(None, gen_sd, sched, first[1].cpu().numpy(), input_code=True, resize=False)[0]) <= 1e-4
+        imgs, lats = run_on_batch(xt, net, opts, avg, landmarks_transform=ltt)
+    assert _sg3abi.launch_count - n0 > 300, 'the loop did not run on the HIP kernels'
+    for it in range(3):
+        got = np.stack([lats[i][it] for i in range(2)])
+        assert maxabs(got, lats_o[it]) <= 2e-4 * float(np.abs(lats_o[it]).max()), (it, maxabs(got, lats_o[it]))
+        img = torch.stack([imgs[i][it] for i in range(2)]).cpu().numpy()
+        assert maxabs(img, imgs_o[it]) <= 1e-4, (it, maxabs(img, imgs_o[it]))
+    if stage < n_styles - 1:                                                # styles beyond the stage carry the base code only
+        assert np.array_equal(lats[0][0][stage + 1] - lat_avg.reshape(-1), lats[0][0][n_styles - 1] - lat_avg.reshape(-1))
+
+
+def test_run_on_batch_survives_weight_updates_after_graph_capture():
+    """a captured ReStyle step goes stale when the decoder is tuned (PTI / load_state_dict / an optimiser step).
+    run_on_batch must then drop the graph and give the eager loop's result for the NEW weights instead of raising; a
+    ShardedInversion built afterwards re-captures."""
+    from sg3_runtime import GraphedReStyleStep
+    from sg3_runtime.sharded import ShardedInversion
+    from utils.inference_utils import get_average_image, run_on_batch
+    net, opts, *_ = build_restyle_pair('Rmini', device=DEV, n_iters=3)
+    x = torch.from_numpy(_frames(3, seed=6)).to(DEV)
+    with torch.no_grad():
+        avg = get_average_image(net)
+        net.graphed_step = GraphedReStyleStep(net, 3)
+        assert not net.graphed_step.is_stale()
+        before = run_on_batch(x, net, opts, avg)
+    w = getattr(net.decoder.synthesis, net.decoder.synthesis.layer_names[2]).weight
+    opt = torch.optim.SGD([w.requires_grad_(True)], lr=0.5)
+    w.grad = torch.ones_like(w) * 0.05
+    opt.step()                                                                          # in-place update: _version moves on
+    w.requires_grad_(False)
+    assert net.graphed_step.is_stale()
+    with torch.no_grad():
+        after = run_on_batch(x, net, opts, avg)                                        # must not raise
+        assert net.graphed_step is None                                                # dropped, logged once
+        eager = run_on_batch(x, net, opts, avg)
+    for i in range(3):
+        assert np.array_equal(after[1][i][2], eager[1][i][2])
+        assert torch.equal(after[0][i][2], eager[0][i][2])
+    assert maxabs(after[0][0][2].cpu().numpy(), before[0][0][2].cpu().numpy()) > 1e-4   # the new weights are what was rendered
+    # the device-resident form used by the sharded path: final latents only, equal to the loop's last step
+    with torch.no_grad():
+        sh = ShardedInversion(net, opts, batch_size=3)
+        assert net.graphed_step is not None and not net.graphed_step.is_stale()        # re-captured on the new weights
+        lat, (a, b) = sh.invert(x.cpu())
+    assert (a, b) == (0, 3) and lat.is_cuda
+    assert maxabs(lat.cpu().numpy(), np.stack([eager[1][i][2] for i in range(3)])) <= 1e-5 * max(1.0, float(np.abs(eager[1][0][2]).max()))

@@ -1,0 +1,54 @@
+"""Audit of the hand-issued loads of modconv_f23_kernel in the compiler's output (hipcc -save-temps .s):
+between an inline-asm buffer_load and the inline-asm `s_waitcnt vmcnt` that follows it in the text, no instruction may mention
+the load's destination registers (hipcc treats an asm load's destination as written when the load is ISSUED, so a copy, spill or
+read placed there moves stale data: cdna_hip_programming.md section 5.7 item 1).  Also reports scratch use.
+
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 -Istylegan3-editing_amd/csrc -c stylegan3-editing_amd/csrc/sg3_modconv_f23.hip -save-temps -o /tmp/x.o
+    python tools/audit_f23_asm.py sg3_modconv_f23-hip-amdgcn-amd-amdhsa-gfx950.s
+"""
+import re
+import sys
+
+text = open(sys.argv[1]).read().split('\n')
+kern = None
+bad = 0
+pending = {}          # register number -> line of the load
+in_asm = False
+for ln, line in enumerate(text, 1):
+    m = re.match(r'^(_ZN3sg318modconv_f23_kernel\w+):', line)
+    if m:
+        kern, pending = m.group(1), {}
+    if kern is None:
+        continue
+    if 's_endpgm' in line:
+        kern = None
+        continue
+    if '#ASMSTART' in line:
+        in_asm = True
+        continue
+    if '#ASMEND' in line:
+        in_asm = False
+        continue
+    code = line.split(';')[0]
+    if in_asm and 'buffer_load' in code:
+        d = re.search(r'buffer_load_\w+\s+v\[(\d+):(\d+)\]|buffer_load_\w+\s+v(\d+)', code)
+        lo, hi = (int(d.group(1)), int(d.group(2))) if d.group(1) else (int(d.group(3)), int(d.group(3)))
+        for r in range(lo, hi + 1):
+            pending[r] = ln
+        continue
+    if in_asm and 's_waitcnt' in code and 'vmcnt' in code:
+        pending = {}
+        continue
+    if 'scratch_' in code:
+        print(f'{kern}: scratch access at line {ln}: {code.strip()}'); bad += 1
+    if not pending or not code.strip() or code.strip().startswith('.'):
+        continue
+    regs = set()
+    for a, b in re.findall(r'v\[(\d+):(\d+)\]', code):
+        regs.update(range(int(a), int(b) + 1))
+    regs.update(int(r) for r in re.findall(r'\bv(\d+)\b', code))
+    hit = sorted(r for r in regs if r in pending)
+    if hit:
+        print(f'{kern}: line {ln} touches v{hit} loaded at line {pending[hit[0]]} before its wait: {code.strip()}'); bad += 1
+print('audit:', 'CLEAN' if bad == 0 else f'{bad} finding(s)')
+sys.exit(1 if bad else 0)

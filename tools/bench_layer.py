@@ -22,11 +22,14 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--dtype', default='float32')
     ap.add_argument('--precision', default='f16x3')
+    ap.add_argument('--f23', default=None, choices=['on', 'off', 'auto'], help='transform-domain 3x3 kernel (modulated_conv.f23)')
     a = ap.parse_args()
     from models.stylegan3.networks_stylegan3 import Generator
     from synth_weights import CONFIGS
     from torch_utils.ops import filtered_lrelu, modulated_conv
     modulated_conv.precision = a.precision
+    if a.f23 is not None:
+        modulated_conv.f23 = a.f23
     dev = 'cuda:0'
     G = Generator(**CONFIGS['T1024']).eval().requires_grad_(False)
     dt = getattr(torch, a.dtype)
