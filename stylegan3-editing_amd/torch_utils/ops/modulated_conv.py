@@ -76,8 +76,11 @@ def _f23_wanted(ci, co, h, wd, padding):
     thin layers (few K chunks per tile, HBM-bound) and narrow planes stay on the direct kernel."""
     if f23 == 'on':
         return True
+    # measured at FFHQ-1024 config T, batch 8 (tools/bench_layer.py, same box): L3 / L4 (512 -> 512 @ 54^2 / 86^2) 445 -> 346 us, L5 953 -> 814,
+    # L6 2450 -> 1921, L7 (512 -> 323) 1702 -> 1516, L8 (323 -> 203) 2310 -> 2015, L9 (203 -> 128) 856 -> 729; the thin layers lose:
+    # L10 (128 -> 81: 8 chunks per tile) 1415 -> 1483, L11 2439 -> 2393 (a tie), and the 38-column planes of L0-L2 fill 59 % of two column tiles
     ow = wd + 2 * padding - 2
-    return ci >= 128 and co >= 96 and ow >= 64
+    return ci >= 192 and co >= 96 and ow >= 48
 
 
 class _Prepared:

@@ -32,6 +32,8 @@ for ln, line in enumerate(text, 1):
     code = line.split(';')[0]
     if in_asm and 'buffer_load' in code:
         d = re.search(r'buffer_load_\w+\s+v\[(\d+):(\d+)\]|buffer_load_\w+\s+v(\d+)', code)
+        if d is None:
+            continue                                       # destination in the accumulator file: not compiler-visible
         lo, hi = (int(d.group(1)), int(d.group(2))) if d.group(1) else (int(d.group(3)), int(d.group(3)))
         for r in range(lo, hi + 1):
             pending[r] = ln
@@ -39,6 +41,8 @@ for ln, line in enumerate(text, 1):
     if in_asm and 's_waitcnt' in code and 'vmcnt' in code:
         pending = {}
         continue
+    if not in_asm and 'v_accvgpr' in code:
+        print(f'{kern}: compiler-generated accumulator-register access at line {ln}: {code.strip()}'); bad += 1
     if 'scratch_' in code:
         print(f'{kern}: scratch access at line {ln}: {code.strip()}'); bad += 1
     if not pending or not code.strip() or code.strip().startswith('.'):

@@ -23,9 +23,9 @@ int main(int argc, char** argv) {
         maxW = std::max(maxW, (size_t)sg3::f23_packed_floats(L.O, L.I));
     }
     float *x, *out, *sIn, *dcoef, *wp; unsigned long long* stamps;
-    const size_t stampWgs = 1u << 16;
+    const size_t stampWgs = 1u << 16;                 // 64 u64 per workgroup in each half of the buffer
     hipMalloc(&x, maxIn * 4); hipMalloc(&out, maxOut * 4); hipMalloc(&sIn, N * 512 * 4); hipMalloc(&dcoef, N * 512 * 4); hipMalloc(&wp, maxW * 4);
-    hipMalloc(&stamps, stampWgs * 64 * 8);
+    hipMalloc(&stamps, (size_t)2 * stampWgs * 64 * 8);
     {
         std::vector<float> h(maxIn);
         unsigned s = 12345u;
@@ -54,22 +54,26 @@ int main(int argc, char** argv) {
         }
         hipDeviceSynchronize();
         // the grid of the launch: recompute as launch_conv_f23 does is not needed -- count the workgroups that wrote a clock
-        std::vector<unsigned long long> h(stampWgs * 64);
+        std::vector<unsigned long long> h((size_t)2 * stampWgs * 64);
         hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
-        hipMemset(stamps, 0, stampWgs * 64 * 8);
-        double sum[2][4] = {}; size_t cnt[2] = {}; std::vector<double> ghz;
+        hipMemset(stamps, 0, (size_t)2 * stampWgs * 64 * 8);
+        double sum[2][4] = {}, hs[2][5] = {}; size_t cnt[2] = {}; std::vector<double> ghz;
         const int nch = (L.I + 15) / 16;
         for (size_t wg = 0; wg < stampWgs; wg++)
             for (int w = 0; w < 8; w++) {
                 const unsigned long long* o = &h[(wg * 8 + w) * 8];
                 if (o[5] < 50) continue;
                 for (int k = 0; k < 4; k++) sum[w >> 2][k] += (double)o[k] / nch;
+                for (int k = 0; k < 5; k++) hs[w >> 2][k] += (double)h[(1u << 22) + (wg * 8 + w) * 8 + k] / nch;
                 cnt[w >> 2]++; ghz.push_back((double)o[4] / (double)o[5] * 0.1);
             }
         std::sort(ghz.begin(), ghz.end());
         printf("%-20s %8.1f %6zu | %6.0f %6.0f %6.0f %6.0f     | %6.0f %6.0f %6.0f %6.0f     | %.3f\n", L.name, ms / 10 * 1e3, cnt[0] / 4,
                sum[0][0] / cnt[0], sum[0][1] / cnt[0], sum[0][2] / cnt[0], sum[0][3] / cnt[0],
                sum[1][0] / cnt[1], sum[1][1] / cnt[1], sum[1][2] / cnt[1], sum[1][3] / cnt[1], ghz.empty() ? 0.0 : ghz[ghz.size() / 2]);
+        printf("    staging block (wait B | stage | request B | land A | request A): early %5.0f %5.0f %5.0f %5.0f %5.0f   late %5.0f %5.0f %5.0f %5.0f %5.0f\n",
+               hs[0][0] / cnt[0], hs[0][1] / cnt[0], hs[0][2] / cnt[0], hs[0][3] / cnt[0], hs[0][4] / cnt[0],
+               hs[1][0] / cnt[1], hs[1][1] / cnt[1], hs[1][2] / cnt[1], hs[1][3] / cnt[1], hs[1][4] / cnt[1]);
         fflush(stdout);
     }
     return 0;
