@@ -68,11 +68,34 @@ def flrelu_algorithmic_bytes(G, batch, elem_size=4):
     return total, per_layer
 
 
+def conv_flop_table(G, batch):
+    """Per modulated convolution of one synthesis forward (input mix first): (algorithmic FLOP = 2 I O k^2 out^2 per image x batch,
+    matrix-core products ISSUED per fp32 product of the algorithm).  Issued factor: 3 for the split-precision kernels (hi*hi + hi*lo +
+    lo*hi), 2 where the transform-domain 3x3 kernel runs (12 instead of 18 contractions per output pair, each still three products),
+    0 for the ToRGB layer (no matrix cores)."""
+    from torch_utils import _sg3abi as abi
+    from torch_utils.ops import modulated_conv as mc
+    lib = abi.load()
+    inp = G.synthesis.input
+    rows = [(2.0 * inp.channels * inp.channels * int(inp.size[0]) * int(inp.size[1]) * batch, 3.0)]
+    for name in G.synthesis.layer_names:
+        layer = getattr(G.synthesis, name)
+        k, ci, co, h = layer.conv_kernel, layer.in_channels, layer.out_channels, int(layer.in_size[0])
+        s = h + k - 1
+        factor = 3.0
+        if layer.is_torgb:
+            factor = 0.0
+        elif k == 3 and mc.f23 != 'off' and mc._f23_wanted(ci, co, h, h, k - 1) and lib.sg3_modconv_f23_supported(abi.SG3_F32, ci, co, h, h, 3, k - 1, 0):
+            factor = 2.0
+        rows.append((2.0 * ci * co * k * k * s * s * batch, factor))
+    return rows
+
+
 class KernelTimer:
     """Brackets every filtered_lrelu / modulated_conv2d ABI launch with HIP events on the launch stream."""
 
     def __init__(self):
-        self.records = {'filtered_lrelu': [], 'modulated_conv2d': []}
+        self.records = {'filtered_lrelu': [], 'modulated_conv2d': [], 'conv2d_wgrad': []}
         self.enabled = False
 
     def install(self):
@@ -81,6 +104,17 @@ class KernelTimer:
         timer = self
         orig_f = _hip_plugins.FilteredLreluPlugin.filtered_lrelu
         orig_c = modulated_conv._launch
+        orig_w = modulated_conv._weight_gradient
+
+        def timed_wgrad(*a, **k):
+            if not timer.enabled:
+                return orig_w(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_w(*a, **k)
+            e1.record()
+            timer.records['conv2d_wgrad'].append((e0, e1))
+            return out
 
         def timed_flrelu(x, *a, **k):
             if not timer.enabled:
@@ -104,6 +138,11 @@ class KernelTimer:
 
         _hip_plugins.FilteredLreluPlugin.filtered_lrelu = staticmethod(timed_flrelu)
         modulated_conv._launch = timed_conv
+        modulated_conv._weight_gradient = timed_wgrad
+
+    def reset(self):
+        for v in self.records.values():
+            v.clear()
 
     def total_ms(self, key):
         return sum(e0.elapsed_time(e1) for e0, e1 in self.records[key])
@@ -142,7 +181,7 @@ def kernel_source_sha():
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
-def bench_inversion(G, device, rank, world, frames_per_gpu=16, restyle_steps=5, reps=2, decoder='T-1024'):
+def bench_inversion(G, device, rank, world, frames_per_gpu=16, restyle_steps=5, reps=2, decoder='T-1024', timer=None):
     """Secondary measurement (BASELINE metric, second half): ReStyle-pSp inversion frames/s.  Every rank inverts its own
     contiguous range of synthetic 256x256 frames (IR-SE50 encoder with seeded synthetic weights -> 5 refinement steps,
     each one encoder forward + one FFHQ-1024 synthesis forward), then the final latents are all-gathered (RCCL)."""
@@ -186,16 +225,39 @@ def bench_inversion(G, device, rank, world, frames_per_gpu=16, restyle_steps=5, 
         torch.cuda.synchronize()
     enc_ms = e0.elapsed_time(e1) / 5
     enc_tflops = ENCODER_GFLOP_PER_IMAGE * frames_per_gpu / enc_ms         # GFLOP / ms = TFLOP/s
-    encoder = {'bound': 'mfma', 'kernel': 'conv2d_f16x3_kernel (IR-SE50 trunk) + head GEMMs', 'achieved': 3 * enc_tflops, 'peak': MFMA_F16_PEAK_TFLOPS,
-               'unit': 'TFLOP/s', 'frac': 3 * enc_tflops / MFMA_F16_PEAK_TFLOPS, 'algorithmic': enc_tflops,
+    # `achieved` / `frac`: ALGORITHMIC fp32 FLOP rate against the dense fp16 MFMA peak; `issued` / `issued_frac`: the matrix-core work
+    # the split-precision kernels issue for it (three fp16 products per fp32 product)
+    encoder = {'bound': 'mfma', 'kernel': 'conv2d_f16x3_kernel (IR-SE50 trunk) + head GEMMs', 'achieved': enc_tflops, 'peak': MFMA_F16_PEAK_TFLOPS,
+               'unit': 'TFLOP/s', 'frac': enc_tflops / MFMA_F16_PEAK_TFLOPS, 'issued': 3 * enc_tflops, 'issued_frac': 3 * enc_tflops / MFMA_F16_PEAK_TFLOPS,
                'algorithmic_flop_per_image': ENCODER_GFLOP_PER_IMAGE * 1e9, 'ms_per_forward': enc_ms, 'batch': frames_per_gpu}
+    # the decoder's filtered_lrelu stages at this batch (config R: the radial instantiations), HIP events around every launch of an
+    # eager forward: algorithmic bytes C (in^2 + out^2) 4 per layer / their summed duration
+    roofline = None
+    if timer is not None:
+        ws16 = torch.randn([frames_per_gpu, G.num_ws, G.w_dim], device=device)
+        fl_bytes, fl_layers = flrelu_algorithmic_bytes(G, frames_per_gpu)
+        with torch.no_grad():
+            G.synthesis.input.transform = torch.eye(3, device=device)
+            G.synthesis(ws16, noise_mode='const', force_fp32=True)
+            timer.reset(); timer.enabled = True
+            for _ in range(3):
+                G.synthesis(ws16, noise_mode='const', force_fp32=True)
+            torch.cuda.synchronize()
+            timer.enabled = False
+        fl_ms = timer.median_step_ms('filtered_lrelu', len(fl_layers))
+        gbs = fl_bytes / (fl_ms * 1e-3) / 1e9 if fl_ms > 0 else 0.0
+        radial = any(getattr(G.synthesis, nm).down_radial for nm in fl_layers)
+        roofline = {'bound': 'hbm', 'kernel': 'flrelu_stream_kernel' + (' (radial 12x12 down filters)' if radial else ''), 'achieved': gbs, 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_bytes_per_forward': fl_bytes,
+                    'kernel_ms_per_forward': fl_ms, 'batch': frames_per_gpu}
+        timer.reset()
     return dict(metric='ReStyle-pSp video-inversion frames/sec', value=n_frames * reps / float(t.item()), unit='frames/s',
-                frames_per_gpu=frames_per_gpu, restyle_steps=restyle_steps, scaling='weak', encoder=encoder,
+                frames_per_gpu=frames_per_gpu, restyle_steps=restyle_steps, scaling='weak', encoder=encoder, roofline=roofline,
                 workload=f'IR-SE50 encoder + FFHQ-1024 config-{decoder} decoder (fp32), 5 ReStyle steps per frame, frames sharded over '
                          'ranks, all-gather of [F,16,512] latents; synthetic weights')
 
 
-def bench_pti_step(device, cfg='T1024', steps=4):
+def bench_pti_step(device, cfg='T1024', steps=4, timer=None):
     """One pivotal-tuning step (reference run_pti_images.py:126-139): fp32 synthesis forward with sign write, MSE, backward
     through the fused adjoint / gradient kernels, Adam over the synthesis weights; batch 1, FFHQ-1024."""
     from synth_weights import synth_ws
@@ -218,12 +280,32 @@ def bench_pti_step(device, cfg='T1024', steps=4):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    out = {'steps_per_s': 1.0 / dt, 'ms_per_step': dt * 1e3, 'batch': 1}
+    if timer is not None:
+        # matrix-core work of one step: forward, data gradient (the forward kernels with the scale vectors exchanged) and weight gradient
+        # each cost the forward's FLOP (the first layers' data gradients are not needed: counted anyway, a few %); time = the launches
+        # of modulated_conv._launch (forward + data gradient) and _weight_gradient between HIP events
+        timer.reset(); timer.enabled = True
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        timer.enabled = False
+        conv_ms = (timer.total_ms('modulated_conv2d') + timer.total_ms('conv2d_wgrad')) / 2
+        rows = conv_flop_table(G, 1)
+        alg = 3.0 * sum(f for f, _ in rows)
+        issued = sum(f * (2 * k + 3.0 * (k > 0)) for f, k in rows)          # forward + data gradient at the layer's factor, weight gradient at 3
+        tf = alg / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'modconv (forward, data gradient) + wgrad_f16x3_kernel', 'achieved': tf, 'peak': MFMA_F16_PEAK_TFLOPS,
+                           'unit': 'TFLOP/s', 'frac': tf / MFMA_F16_PEAK_TFLOPS, 'issued_frac': issued / (conv_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS if conv_ms > 0 else 0.0,
+                           'algorithmic_flop_per_step': alg, 'kernel_ms_per_step': conv_ms,
+                           'wgrad_ms_per_step': timer.total_ms('conv2d_wgrad') / 2}
+        timer.reset()
     del G, opt
     torch.cuda.empty_cache()
-    return {'steps_per_s': 1.0 / dt, 'ms_per_step': dt * 1e3, 'batch': 1}
+    return out
 
 
-def bench_extras(G, ws, device, steps=5):
+def bench_extras(G, ws, device, steps=5, timer=None):
     """Secondary single-GPU measurements (eager launches, not the headline): the reference's default mixed-precision
     execution of the same workload, and config R (1x1 convolutions, radial down filters) at 1024 and 512."""
     from synth_weights import synth_ws
@@ -242,8 +324,8 @@ def bench_extras(G, ws, device, steps=5):
 
     G.synthesis.input.transform = torch.eye(3, device=device)     # the inversion measurement leaves per-frame transforms behind
     out = {'T1024_mixed_fp16': run(G, ws)}
-    out['T1024_pti_step'] = bench_pti_step(device, 'T1024')
-    out['R1024_pti_step'] = bench_pti_step(device, 'R1024')
+    out['T1024_pti_step'] = bench_pti_step(device, 'T1024', timer=timer)
+    out['R1024_pti_step'] = bench_pti_step(device, 'R1024', timer=timer)
     for cfg, batch in (('R1024', 4), ('R512', 8)):
         gen = build_generator(cfg, device)
         w = torch.from_numpy(synth_ws(batch, gen.num_ws, gen.w_dim, seed=1)).to(device)
@@ -424,13 +506,13 @@ def main(argv=None):
         # the reference's default decoder is config R (models/stylegan3/model.py:42-54); the config-T
         # decoder of the headline workload is measured beside it
         G_r = build_generator('R1024', device)
-        inversion = bench_inversion(G_r, device, rank, world, decoder='R-1024')
+        inversion = bench_inversion(G_r, device, rank, world, decoder='R-1024', timer=timer if rank == 0 else None)
         del G_r
         torch.cuda.empty_cache()
-        inversion_t = bench_inversion(G, device, rank, world, decoder='T-1024')
+        inversion_t = bench_inversion(G, device, rank, world, decoder='T-1024', timer=None)
     extras = None
     if not args.no_extras and world == 1 and args.config == 'T1024':
-        extras = bench_extras(G, ws, device)
+        extras = bench_extras(G, ws, device, timer=timer)
 
     if rank == 0:
         n_layers = len(G.synthesis.layer_names)
@@ -449,13 +531,11 @@ def main(argv=None):
                 tj = json.load(f)
             if tj.get('kernel_source_sha') == kernel_source_sha():
                 traffic = tj['traffic_bytes_per_step']
-        inp = G.synthesis.input
-        conv_flop = 2 * inp.channels * inp.channels * int(inp.size[0]) * int(inp.size[1]) * args.batch
-        for name in G.synthesis.layer_names:
-            layer = getattr(G.synthesis, name)
-            s = int(layer.in_size[0]) + layer.conv_kernel - 1
-            conv_flop += 2 * layer.in_channels * layer.out_channels * layer.conv_kernel ** 2 * s * s * args.batch
+        rows = conv_flop_table(G, args.batch)
+        conv_flop = sum(f for f, _ in rows)
+        conv_issued = sum(f * k for f, k in rows)
         conv_tflops = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        issued_tflops = conv_issued / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         out = {
             'metric': 'FFHQ-1024 StyleGAN3-T synthesis imgs/sec', 'value': args.batch * world * args.steps / dt, 'unit': 'imgs/s',
             'n_gpus': world, 'world_size_observed': dist.get_world_size() if world > 1 else 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
@@ -466,11 +546,15 @@ def main(argv=None):
             'roofline': {'bound': 'hbm', 'kernel': 'flrelu_stream_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_step': total_bytes, 'kernel_ms_per_step': fl_ms},
-            # second roofline, same shape: the modulated convolutions against the dense fp16 MFMA peak.  `achieved` counts the
-            # MFMA work issued (three fp16 products per fp32 product of the algorithm); `algorithmic` is the fp32 FLOP rate
-            'modconv': {'bound': 'mfma', 'kernel': 'modconv_f16x3_kernel (+input mix, ToRGB 1x1)', 'achieved': 3 * conv_tflops, 'peak': MFMA_F16_PEAK_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': 3 * conv_tflops / MFMA_F16_PEAK_TFLOPS, 'algorithmic': conv_tflops,
-                        'algorithmic_flop_per_step': conv_flop, 'kernel_ms_per_step': conv_ms},
+            # second roofline, same shape: the modulated convolutions against the dense fp16 MFMA peak.  `achieved` / `frac` are the
+            # ALGORITHMIC fp32 FLOP rate (2 I O k^2 out^2 per image and layer); `issued` / `issued_frac` count the fp16 matrix-core work
+            # issued for it: three products per fp32 product in the split-precision kernels, two where the transform-domain 3x3 kernel
+            # (Winograd F(2,3) along x: two thirds of the contractions) runs
+            'modconv': {'bound': 'mfma', 'kernel': 'modconv_f23_kernel / modconv_f16x3_kernel (+input mix, ToRGB 1x1)', 'achieved': conv_tflops,
+                        'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': conv_tflops / MFMA_F16_PEAK_TFLOPS,
+                        'issued': issued_tflops, 'issued_frac': issued_tflops / MFMA_F16_PEAK_TFLOPS,
+                        'algorithmic_flop_per_step': conv_flop, 'kernel_ms_per_step': conv_ms,
+                        'f23_layers': sum(1 for _, k in rows if k == 2.0)},
         }
         out['inversion'] = inversion
         out['inversion_T1024'] = inversion_t

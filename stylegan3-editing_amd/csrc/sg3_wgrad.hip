@@ -16,7 +16,9 @@
 //
 // Work decomposition: a workgroup owns a 64 x 64 (o, i) tile of one sample, a band of dy rows and a group of 32-pixel
 // column segments; its four waves each own one 32 x 32 (o, i) block and ALL taps (nine accumulators), so an A fragment is
-// read once per K step for 27 MFMAs.  Per (row, segment): the dy segment and the new xp row segment are split and staged
+// read once per K step for 27 MFMAs.  Tiles with fewer than four real 32 x 32 blocks (the thin 1024^2 layers: 32 -> 32 is ONE
+// block, 51 -> 32 two) give the idle waves a share of the TAPS instead of a block of channel padding: two waves per block take
+// 5 + 4 taps, four waves 3 + 2 + 2 + 2 (a wave-uniform range test around each tap's three MFMAs; staging is unchanged).  Per (row, segment): the dy segment and the new xp row segment are split and staged
 // in LDS (the three xp rows a dy row touches live in a ring, so every xp row is staged once per band); the column shift
 // kx of a tap is taken in registers from a 16-half window (two aligned ds_read_b128): kx = 2 is a register rename, kx = 1
 // four v_alignbyte.  The K dimension is split over workgroups; partial sums go to [split][n][tap][o][i] (coalesced
@@ -57,13 +59,22 @@ wgrad_f16x3_kernel(WgradParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int ob = wave & 1, ib = wave >> 1;
 
     int t = blockIdx.x;
     const int it = t % p.iTiles; t /= p.iTiles;
     const int ot = t % p.oTiles; const int n = t / p.oTiles;
     const int band = blockIdx.y, sg = blockIdx.z;
     const int o0 = ot * 64, i0 = it * 64;
+    // real 32 x 32 blocks of this tile and the waves' shares: (block, tap range) -- all wave-uniform
+    const int nOb = p.O - o0 > 32 ? 2 : 1, nIb = p.I - i0 > 32 ? 2 : 1;
+    const int wpb = (KS == 3) ? 4 / (nOb * nIb) : 1;                       // waves per block: 1 | 2 | 4
+    const int blk = wave / wpb, sub = wave % wpb;
+    const int ob = blk % nOb, ib = blk / nOb;
+    const bool blockReal = blk < nOb * nIb;                                // 1x1 kernels keep one block per wave: padding blocks idle
+    int tLo = 0, tHi = TAPS;
+    if (wpb == 2) { tLo = sub ? 5 : 0; tHi = sub ? 9 : 5; }
+    else if (wpb == 4) { tLo = sub ? 1 + 2 * sub : 0; tHi = 3 + 2 * sub; }
+    if (!blockReal) tHi = tLo = 0;
     const int y0 = band * p.bandRows, y1 = min(y0 + p.bandRows, p.OH);
     const int seg0 = sg * p.segsPerGroup, seg1 = min(seg0 + p.segsPerGroup, p.nSegs);
 
@@ -126,6 +137,7 @@ wgrad_f16x3_kernel(WgradParams p) {
     };
     // (ky, all kx) of one K step: the 16-half window of this lane's input row, then the three column shifts
     auto taps_of_row = [&](int slot, int ky, int k0, v8h ah, v8h al) {
+        if (ky * KS + KS <= tLo || ky * KS >= tHi) return;                 // none of this filter row's taps is this wave's
         const _Float16* src = sX + slot * 2 * XPLANE + (ib * 32 + li) * XP + k0 + 8 * lh;
         const u32x4 h0 = *reinterpret_cast<const u32x4*>(src), h1 = *reinterpret_cast<const u32x4*>(src + 8);
         const u32x4 l0 = *reinterpret_cast<const u32x4*>(src + XPLANE), l1 = *reinterpret_cast<const u32x4*>(src + XPLANE + 8);
@@ -146,6 +158,7 @@ wgrad_f16x3_kernel(WgradParams p) {
             }
             const v8h fbh = __builtin_bit_cast(v8h, bh), fbl = __builtin_bit_cast(v8h, bl);
             const int tp = ky * KS + kx;
+            if (tp < tLo || tp >= tHi) continue;                           // wave-uniform
             acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fbh, acc[tp], 0, 0, 0);
             acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fbl, acc[tp], 0, 0, 0);
             acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fbh, acc[tp], 0, 0, 0);
@@ -179,12 +192,14 @@ wgrad_f16x3_kernel(WgradParams p) {
     float* outp = p.partial + ((size_t)split * p.N + n) * TAPS * p.O * p.I;
     const int gi = i0 + ib * 32 + li;
 #pragma unroll
-    for (int tp = 0; tp < TAPS; tp++)
+    for (int tp = 0; tp < TAPS; tp++) {
+        if (tp < tLo || tp >= tHi) continue;                               // another wave's tap (or a padding block)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int go = o0 + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (go < p.O && gi < p.I) outp[((size_t)tp * p.O + go) * p.I + gi] = acc[tp][r] * inv;
         }
+    }
 }
 
 template <typename T, int KS>

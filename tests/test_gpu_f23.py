@@ -120,3 +120,40 @@ def test_f23_unsupported_shapes_fall_back():
         y = mc.modulated_conv2d(T(x), T(w), T(s), demodulate=True, padding=2, x_bound=8.0)
     ref = O.modulated_conv2d(x, w, s, True, 2, None)
     assert maxabs(y.cpu().numpy(), ref) <= 3e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_f23_repeated_with_shifting_allocations():
+    """Regression for a hazard that only showed with cold, freshly allocated operands: the hand-issued loads of the kernel read
+    scalar registers that hipcc had just reloaded from a spill (VALU-written SGPR -> vector-memory read needs 5 wait states; the
+    requests now open with s_nop 4).  Many launches on new allocations, every tile height, against the direct kernel."""
+    from torch_utils.ops import modulated_conv as mc
+    g = torch.Generator(device=DEV).manual_seed(3)
+    shapes = [(2, 64, 64, 30, 30, 2), (1, 323, 203, 22, 26, 2), (2, 81, 51, 40, 70, 2), (3, 17, 130, 35, 34, 0)]
+    worst = 0.0
+    for rep in range(12):
+        for tn in (4, 5, 7):
+            for (n, ci, co, h, w, pad) in shapes:
+                x = torch.randn(n, ci, h, w, device=DEV, generator=g) * 3
+                wt = torch.randn(co, ci, 3, 3, device=DEV, generator=g)
+                s = torch.rand(n, ci, device=DEV, generator=g) + 0.5
+                junk = torch.empty(1 << (20 + rep % 5), device=DEV)              # moves the next allocations
+                with _f23('off') as m:
+                    ref = m.modulated_conv2d(x, wt, s, demodulate=True, padding=pad, x_bound=16.0)
+                with _f23('on', tn) as m:
+                    got = m.modulated_conv2d(x, wt, s, demodulate=True, padding=pad, x_bound=16.0)
+                worst = max(worst, float((got - ref).abs().max()) / float(ref.abs().max()))
+                del junk
+    assert worst <= 5e-6, worst
+
+
+def test_f23_many_tiles_per_workgroup():
+    """More tiles than CUs: every persistent workgroup walks several tiles (accumulators re-zeroed, LDS images reused after the
+    output exchange); sizes whose tile count is not a multiple of 8 and of the CU count."""
+    from oracle import oracle as O
+    n, ci, co, h, w = 3, 32, 200, 118, 90
+    x = np.clip(rand(5, n, ci, h, w) * 2, -8, 8).astype(np.float32); wt = rand(6, co, ci, 3, 3); s = rand(7, n, ci) + 1
+    ref = O.modulated_conv2d(x.astype(np.float64), wt.astype(np.float64), s.astype(np.float64), True, 2, None)
+    for tn in (4, 7):
+        with _f23('on', tn) as mc:
+            y = mc.modulated_conv2d(T(x), T(wt), T(s), demodulate=True, padding=2, x_bound=8.0)
+        assert maxabs(y.cpu().numpy(), ref) <= 5e-6 * float(np.abs(ref).max()), tn

@@ -476,7 +476,8 @@ def test_modulated_conv2d_fp16_form(n, ci, co, h, k):
 
 
 @pytest.mark.parametrize('n,ci,co,h,w,k,pad', [(2, 70, 100, 21, 37, 3, 2), (1, 32, 32, 70, 45, 3, 2), (1, 130, 64, 40, 40, 3, 1), (2, 64, 3, 33, 50, 1, 0),
-                                              (1, 200, 161, 30, 30, 1, 0), (1, 16, 16, 150, 150, 3, 2)])
+                                              (1, 200, 161, 30, 30, 1, 0), (1, 16, 16, 150, 150, 3, 2),
+                                              (1, 51, 32, 60, 44, 3, 2), (1, 81, 51, 40, 36, 3, 2)])      # thin tiles: the waves share the taps of one / two blocks
 def test_conv2d_wgrad_kernel(n, ci, co, h, w, k, pad):
     """Per-sample weight gradient kernel against the fp64 definition dW[n,o,i,ky,kx] = sum dy[n,o,y,x] xpad[n,i,y+ky,x+kx];
     operands of very different magnitude (activations O(100), gradients O(1e-6)) exercise the power-of-two scaling."""

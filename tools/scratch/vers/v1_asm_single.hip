@@ -29,9 +29,7 @@
 #include "sg3_common.h"
 #include "sg3_split.h"
 #include "sg3_modconv_f23.h"
-#include <algorithm>
 #include <cstdlib>
-#include <type_traits>
 
 namespace sg3 {
 
@@ -54,41 +52,6 @@ unsigned long long* g_f23_stamps = nullptr;
 #define F23_STAMP(t) do { } while (0)
 #endif
 
-// ---- accumulator-register helpers: every register is named literally (template integers spliced into the text) ----
-// layout: a[0:23] current A fragments (fragment f = 2 ky + (hi | lo) in a[4f : 4f+3]), a[24:47] landing buffer of the next A request,
-// a[48 + 16 b : 63 + 16 b] the accumulator block of tile row b.
-template <int B, int F> __device__ __forceinline__ void f23_mfma(const v8h& bfrag) {
-    asm volatile("v_mfma_f32_32x32x16_f16 a[%c1:%c2], a[%c3:%c4], %0, a[%c1:%c2]" :: "v"(bfrag), "n"(48 + 16 * B), "n"(63 + 16 * B), "n"(4 * F), "n"(4 * F + 3));
-}
-template <int R> __device__ __forceinline__ void f23_acc_zero() { asm volatile("v_accvgpr_write_b32 a[%c0], 0" :: "n"(R)); }
-template <int R> __device__ __forceinline__ float f23_acc_read() { float v; asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "n"(R)); return v; }
-template <int R, int N> struct F23Seq {
-    static __device__ __forceinline__ void zero() { f23_acc_zero<R>(); F23Seq<R + 1, N - 1>::zero(); }
-    static __device__ __forceinline__ void read(float* dst) { *dst = f23_acc_read<R>(); F23Seq<R + 1, N - 1>::read(dst + 1); }
-};
-template <int R> struct F23Seq<R, 0> {
-    static __device__ __forceinline__ void zero() {}
-    static __device__ __forceinline__ void read(float*) {}
-};
-// the products of one B fragment (patch row Q) with the filter rows ky = 0..2 -> tile rows Q - ky: lo(A) hi(B), hi(A) lo(B), hi(A) hi(B)
-template <int TN, int Q> __device__ __forceinline__ void f23_mfma_row(const v8h& bh, const v8h& bl) {
-    if constexpr (Q >= 0 && Q < TN)         f23_mfma<(Q >= 0 && Q < TN) ? Q : 0, 1>(bh);
-    if constexpr (Q - 1 >= 0 && Q - 1 < TN) f23_mfma<(Q - 1 >= 0 && Q - 1 < TN) ? Q - 1 : 0, 3>(bh);
-    if constexpr (Q - 2 >= 0 && Q - 2 < TN) f23_mfma<(Q - 2 >= 0 && Q - 2 < TN) ? Q - 2 : 0, 5>(bh);
-    if constexpr (Q >= 0 && Q < TN)         f23_mfma<(Q >= 0 && Q < TN) ? Q : 0, 0>(bl);
-    if constexpr (Q - 1 >= 0 && Q - 1 < TN) f23_mfma<(Q - 1 >= 0 && Q - 1 < TN) ? Q - 1 : 0, 2>(bl);
-    if constexpr (Q - 2 >= 0 && Q - 2 < TN) f23_mfma<(Q - 2 >= 0 && Q - 2 < TN) ? Q - 2 : 0, 4>(bl);
-    if constexpr (Q >= 0 && Q < TN)         f23_mfma<(Q >= 0 && Q < TN) ? Q : 0, 0>(bh);
-    if constexpr (Q - 1 >= 0 && Q - 1 < TN) f23_mfma<(Q - 1 >= 0 && Q - 1 < TN) ? Q - 1 : 0, 2>(bh);
-    if constexpr (Q - 2 >= 0 && Q - 2 < TN) f23_mfma<(Q - 2 >= 0 && Q - 2 < TN) ? Q - 2 : 0, 4>(bh);
-}
-
-// wave priority: 0 none | 1 matrix phase at priority 1 | 2 waves 4-7 at priority 1 throughout (the second-dispatched wave of every SIMD
-// loses the issue arbitration to the older one: its staging block took 3-4x as long; measured -6 % on L5..L9) | 3 staging block at 1
-#ifndef F23_PRIO_MODE
-#define F23_PRIO_MODE 2
-#endif
-
 template <int TN>
 __global__ void __launch_bounds__(512, 2)
 modconv_f23_kernel(F23Params p) {
@@ -107,27 +70,11 @@ modconv_f23_kernel(F23Params p) {
     const int li = lane & 31, lh = lane >> 5;
     const int rg = li >> 4, pq = li & 15;
 
-    // PERSISTENT workgroups (one per CU: the B images take most of the LDS, so a tile's prologue and epilogue have no co-resident
-    // workgroup to hide behind, and neither has the dispatch of a fresh workgroup): a workgroup walks through its share of the tiles.
-    // Blocks b, b + 8, ... share an XCD; each XCD takes a contiguous range of the logical tile order (M tile fastest, so the M tiles
-    // of one pixel tile -- same input patch -- and neighbouring patches run side by side on one L2), 'slots' tiles at a time.
-    int tFirst, tEnd, tStep;
+    int bid = blockIdx.x;
     {
-        const int G = (int)gridDim.x, b = (int)blockIdx.x, nb = p.totalBlocks;
-        if ((G & 7) == 0) {
-            const int q = nb >> 3, r = nb & 7, xcd = b & 7, slots = G >> 3;
-            const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-            tFirst = start + (b >> 3); tEnd = start + q + (xcd < r ? 1 : 0); tStep = slots;
-        } else { tFirst = b; tEnd = nb; tStep = G; }
-#ifdef SG3_F23_ONE_TILE
-        {   // experiment: one tile per workgroup, grid = tiles (XCD-aware order as before)
-            const int q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
-            tFirst = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k; tEnd = tFirst + 1; tStep = 1;
-        }
-#endif
+        const int nb = p.totalBlocks, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
-    for (int tile = tFirst; tile < tEnd; tile += tStep) {
-    int bid = tile;
     const int mt = bid % p.mTiles; bid /= p.mTiles;
     const int xt = bid % p.xTiles; bid /= p.xTiles;
     const int yt = bid % p.yTiles; const int n = bid / p.yTiles;
@@ -158,13 +105,7 @@ modconv_f23_kernel(F23Params p) {
         const int gy = y0 - p.pad + srow, gx = x0 - p.pad + 2 * spair;
         const bool rowOk = sOk && (unsigned)gy < (unsigned)p.H;
         g0 = rowOk && (unsigned)gx < (unsigned)p.W ? (unsigned)(gy * p.W + gx) * 4u : 0x80000000u;
-        // every sample is requested ONCE: a thread loads its own column pair; the pair to its right arrives from the next lane
-        // through DPP, and only the last pair of a tile row (lane 15 of its 16) requests the two halo columns itself
-#ifdef SG3_F23_NO_DPP
         g1 = rowOk && (unsigned)(gx + 2) < (unsigned)p.W ? (unsigned)(gy * p.W + gx + 2) * 4u : 0x80000000u;
-#else
-        g1 = rowOk && spair == 15 && (unsigned)(gx + 2) < (unsigned)p.W ? (unsigned)(gy * p.W + gx + 2) * 4u : 0x80000000u;
-#endif
     }
     const unsigned gS = (unsigned)(lane & 15) * 4u;                   // style scales: lane c requests channel c of the chunk
     const int sL = srow * 256 + spair * 16 + sch * PLANE;             // + (xi * 2 + part) * 2 * PLANE
@@ -174,63 +115,39 @@ modconv_f23_kernel(F23Params p) {
     // ---- B fragment reads ----
     const int bR = (xi * 4 + lh) * PLANE + (rg * TN) * 256 + pq * 16;  // hi plane of this lane's channel half; lo at + 2 PLANE
 
-    // the kernel's accumulator-register allocation covers what the asm statements name (the highest register named as a clobber sizes
-    // it); the compiler itself stays within its arch VGPRs (AUDIT: no v_accvgpr_* outside the asm statements)
-    if constexpr (TN == 7) asm volatile("" ::: "a159");
-    else if constexpr (TN == 5) asm volatile("" ::: "a127");
-    else asm volatile("" ::: "a111");
-    static_assert(TN == 4 || TN == 5 || TN == 7, "accumulator-register reservation is written for these tile heights");
-    F23Seq<48, 16 * TN>::zero();
+    f32x16 acc[TN];
+#pragma unroll
+    for (int b = 0; b < TN; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[b][r] = 0.f;
 
-    // All vector-memory loads of the K loop are issued and waited for BY HAND (inline asm): the two request streams -- A fragments,
-    // input samples -- are consumed in a different order than they are issued, and hipcc, merging the loop's paths, drains the whole
-    // queue (s_waitcnt vmcnt(0)) in front of each consumer, i.e. waits for the loads it has just issued: 1800-2700 cycles per staging
-    // block instead of ~600 (in-kernel stamps, profiles/r03_f23_stamps.txt).  The counter is in order, so "all but the N youngest" is
-    // exact: N = the loads issued after the group that is needed.
-    //
-    // A fragments live in ACCUMULATOR registers that only this file's asm statements name: a[0:23] = the six fragments of the
-    // current chunk (fragment f = 2 ky + (hi | lo) in a[4f : 4f+3]), a[24:47] = the landing buffer of the next request.  A request
-    // leads its landing by a whole iteration (the loads take 2-3 us under this kernel's own traffic); F23_LAND waits for it and moves
-    // it down (24 v_accvgpr_mov).  The compiler never sees these values, so it cannot copy, spill or reuse a register a load is still
-    // in flight to -- which it did, in three different ways, while the fragments were ordinary asm outputs (AUDIT below).
-    // The input samples (rb, rsc) stay compiler-allocated outputs of their requests; every wait for them names them as read-write
-    // operands, which keeps consumers behind the wait and the registers reserved until then.
+    // All vector-memory loads of the K loop are issued and waited for BY HAND (inline asm): the two request streams -- A fragments
+    // of the next chunk, input samples of the chunk after -- are consumed in a different order than they are issued, and hipcc,
+    // merging the loop's paths, drains the whole queue (s_waitcnt vmcnt(0)) in front of each consumer, i.e. waits for the loads it
+    // has just issued: 1800-2700 cycles per staging block instead of ~600 (in-kernel stamps, profiles/r03_f23_stamps.txt).  The
+    // counter is in order, so "all but the N youngest" is exact: N = the loads issued after the group that is needed.  Every wait
+    // statement names the destination registers as read-write operands, which keeps their consumers behind it.
     f32x2 rb[8][2];
     float rsc;
+    u32x4 af[6];                                                      // A fragments of the current chunk: (ky, hi | lo)
     constexpr int NB = 17, NA = 6;                                    // loads per input request / per fragment request
-#ifdef SG3_F23_WAIT0
-#define F23_CNT(N) "0"
-#else
-#define F23_CNT(N) #N
-#endif
-    // Each request is ONE asm statement that opens with "s_nop 4": hipcc may reload a spilled SGPR with v_readlane right in front
-    // of the statement, and an SGPR written by a VALU instruction needs 5 wait states before a vector-memory instruction reads it
-    // (descriptor or scalar offset) -- the compiler pads that hazard for its own instructions, not for ones inside an asm string.
-    // (Seen with the persistent tile loop, which pushed the kernel into SGPR spills: stale descriptors, wrong samples staged.)
+
+    // Requests are issued on EVERY iteration -- beyond the last chunk with an out-of-range offset, which the range check answers with
+    // zeros without touching memory -- so the queue has the same shape in every iteration (constant wait counts) and the registers
+    // are redefined on every path (no copies of in-flight destinations: see the audit note at the waits).
     auto fetch_a = [&](int ch) {
         const unsigned so = aS + (unsigned)ch * CHUNKB;               // wave-uniform
-        const unsigned vo = ch < p.nch ? aG : 0x80000000u;            // beyond the last chunk: out of range, answered with zeros
-        asm volatile("s_nop 4\n\t"
-                     "buffer_load_dwordx4 a[24:27], %0, %1, %2 offen\n\t"
-                     "buffer_load_dwordx4 a[28:31], %0, %1, %2 offen offset:1024\n\t"
-                     "buffer_load_dwordx4 a[32:35], %0, %1, %2 offen offset:2048\n\t"
-                     "buffer_load_dwordx4 a[36:39], %0, %1, %3 offen\n\t"
-                     "buffer_load_dwordx4 a[40:43], %0, %1, %3 offen offset:1024\n\t"
-                     "buffer_load_dwordx4 a[44:47], %0, %1, %3 offen offset:2048"
-                     :: "v"(vo), "s"(wd), "s"(so), "s"(so + 3 * FRAG)
-                     : "memory", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39",
-                       "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+        const unsigned vo = ch < p.nch ? aG : 0x80000000u;
+#if defined(SG3_F23_BUILTIN) || defined(SG3_F23_BUILTIN_A)
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, (short)0, (int)((unsigned)p.mTiles * (unsigned)p.nch * (unsigned)CHUNKB), 0x00020000);
+#pragma unroll
+        for (int f = 0; f < 6; f++) af[f] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)vo, (int)(so + f * FRAG), 0);
+#else
+#pragma unroll
+        for (int f = 0; f < 6; f++)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(af[f]) : "v"(vo), "s"(wd), "s"(so + f * FRAG) : "memory");
+#endif
     };
-    // wait until all but the N youngest loads have landed, then landing buffer -> current fragments
-#define F23_LAND(N) asm volatile("s_waitcnt vmcnt(" F23_CNT(N) ")\n\t" \
-        "v_accvgpr_mov_b32 a0, a24\n\tv_accvgpr_mov_b32 a1, a25\n\tv_accvgpr_mov_b32 a2, a26\n\tv_accvgpr_mov_b32 a3, a27\n\t" \
-        "v_accvgpr_mov_b32 a4, a28\n\tv_accvgpr_mov_b32 a5, a29\n\tv_accvgpr_mov_b32 a6, a30\n\tv_accvgpr_mov_b32 a7, a31\n\t" \
-        "v_accvgpr_mov_b32 a8, a32\n\tv_accvgpr_mov_b32 a9, a33\n\tv_accvgpr_mov_b32 a10, a34\n\tv_accvgpr_mov_b32 a11, a35\n\t" \
-        "v_accvgpr_mov_b32 a12, a36\n\tv_accvgpr_mov_b32 a13, a37\n\tv_accvgpr_mov_b32 a14, a38\n\tv_accvgpr_mov_b32 a15, a39\n\t" \
-        "v_accvgpr_mov_b32 a16, a40\n\tv_accvgpr_mov_b32 a17, a41\n\tv_accvgpr_mov_b32 a18, a42\n\tv_accvgpr_mov_b32 a19, a43\n\t" \
-        "v_accvgpr_mov_b32 a20, a44\n\tv_accvgpr_mov_b32 a21, a45\n\tv_accvgpr_mov_b32 a22, a46\n\tv_accvgpr_mov_b32 a23, a47\n\ts_nop 1" \
-        ::: "memory", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", \
-            "a19", "a20", "a21", "a22", "a23")
     auto fetch_b = [&](int ch) {
         const bool in = ch < p.nch;
         // the chunk's channel offset rides in the VECTOR offset of the scale request: only that is range checked, and channels beyond I
@@ -248,39 +165,28 @@ modconv_f23_kernel(F23Params p) {
             rb[c][1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)v1, (int)coff, 0));
         }
 #else
-        unsigned cf[8];
+        asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(rsc) : "v"(vs), "s"(sd) : "memory");
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             const int ci = ch * 16 + sch * 8 + c;                       // wave-uniform
-            cf[c] = ci < p.I ? (unsigned)ci * HWb : 0u;                 // padded channels alias channel 0 and meet a zero scale
+            const unsigned coff = ci < p.I ? (unsigned)ci * HWb : 0u;   // padded channels alias channel 0 and meet a zero scale
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(rb[c][0]) : "v"(v0), "s"(xd), "s"(coff) : "memory");
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(rb[c][1]) : "v"(v1), "s"(xd), "s"(coff) : "memory");
         }
-        asm volatile("s_nop 4\n\t"
-                     "buffer_load_dword %0, %9, %10, 0 offen\n\t"
-                     "buffer_load_dwordx2 %1, %11, %13, %14 offen\n\t"
-                     "buffer_load_dwordx2 %2, %12, %13, %14 offen\n\t"
-                     "buffer_load_dwordx2 %3, %11, %13, %15 offen\n\t"
-                     "buffer_load_dwordx2 %4, %12, %13, %15 offen\n\t"
-                     "buffer_load_dwordx2 %5, %11, %13, %16 offen\n\t"
-                     "buffer_load_dwordx2 %6, %12, %13, %16 offen\n\t"
-                     "buffer_load_dwordx2 %7, %11, %13, %17 offen\n\t"
-                     "buffer_load_dwordx2 %8, %12, %13, %17 offen"
-                     : "=&v"(rsc), "=&v"(rb[0][0]), "=&v"(rb[0][1]), "=&v"(rb[1][0]), "=&v"(rb[1][1]), "=&v"(rb[2][0]), "=&v"(rb[2][1]), "=&v"(rb[3][0]), "=&v"(rb[3][1])
-                     : "v"(vs), "s"(sd), "v"(v0), "v"(v1), "s"(xd), "s"(cf[0]), "s"(cf[1]), "s"(cf[2]), "s"(cf[3]) : "memory");
-        asm volatile("s_nop 4\n\t"
-                     "buffer_load_dwordx2 %0, %8, %10, %11 offen\n\t"
-                     "buffer_load_dwordx2 %1, %9, %10, %11 offen\n\t"
-                     "buffer_load_dwordx2 %2, %8, %10, %12 offen\n\t"
-                     "buffer_load_dwordx2 %3, %9, %10, %12 offen\n\t"
-                     "buffer_load_dwordx2 %4, %8, %10, %13 offen\n\t"
-                     "buffer_load_dwordx2 %5, %9, %10, %13 offen\n\t"
-                     "buffer_load_dwordx2 %6, %8, %10, %14 offen\n\t"
-                     "buffer_load_dwordx2 %7, %9, %10, %14 offen"
-                     : "=&v"(rb[4][0]), "=&v"(rb[4][1]), "=&v"(rb[5][0]), "=&v"(rb[5][1]), "=&v"(rb[6][0]), "=&v"(rb[6][1]), "=&v"(rb[7][0]), "=&v"(rb[7][1])
-                     : "v"(v0), "v"(v1), "s"(xd), "s"(cf[4]), "s"(cf[5]), "s"(cf[6]), "s"(cf[7]) : "memory");
 #endif
     };
     // AUDIT after every edit (tools/audit_f23_asm.py on the -save-temps .s): between a hand-issued load and the wait that covers it
     // hipcc must not read or copy the destination registers (it treats them as written when the load is issued).
+#ifdef SG3_F23_WAIT0
+#define F23_CNT(N) "0"
+#else
+#define F23_CNT(N) #N
+#endif
+#if defined(SG3_F23_BUILTIN) || defined(SG3_F23_BUILTIN_A)
+#define F23_WAIT_A(N) do { } while (0)
+#else
+#define F23_WAIT_A(N) asm volatile("s_waitcnt vmcnt(" F23_CNT(N) ")" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]) :: "memory")
+#endif
 #if defined(SG3_F23_BUILTIN) || defined(SG3_F23_BUILTIN_B)
 #define F23_WAIT_B(N) do { } while (0)
 #else
@@ -298,23 +204,12 @@ modconv_f23_kernel(F23Params p) {
         for (int c = 0; c < 8; c++) {
 #ifdef SG3_F23_CSTAGE
             const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rsc), sch * 8 + c));
-            float nx = rb[c][1].x, ny = rb[c][1].y;
-            asm("v_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(nx) : "v"(rb[c][0].x));
-            asm("v_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(ny) : "v"(rb[c][0].y));
-            const float d0 = rb[c][0].x * sc, d1 = rb[c][0].y * sc, d2 = nx * sc, d3 = ny * sc;
+            const float d0 = rb[c][0].x * sc, d1 = rb[c][0].y * sc, d2 = rb[c][1].x * sc, d3 = rb[c][1].y * sc;
             v03[c] = (f32x2){d0 - d2, d1 - d3}; v12[c] = (f32x2){d1 + d2, d2 - d1};
 #else
             const unsigned long long sc2 = (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, rsc), sch * 8 + c);   // low half: the scale
-            // columns (2p+2, 2p+3) = the own pair of the lane to the right (row_shl: lane i takes lane i + 1 of its row of 16; the
-            // last lane of a row has no source and keeps what it loaded: the halo pair)
-            float nx = rb[c][1].x, ny = rb[c][1].y;
-#ifndef SG3_F23_NO_DPP
-            asm("v_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(nx) : "v"(rb[c][0].x));
-            asm("v_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(ny) : "v"(rb[c][0].y));
-#endif
-            const f32x2 right = {nx, ny};
             f32x2 t;
-            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(right), "s"(sc2));
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(rb[c][1]), "s"(sc2));
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(v03[c]) : "v"(rb[c][0]), "s"(sc2), "v"(t));
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] neg_hi:[1,0,0]" : "=v"(v12[c]) : "v"(rb[c][0]), "s"(sc2), "v"(t));
 #endif
@@ -351,77 +246,55 @@ modconv_f23_kernel(F23Params p) {
         f.h = *reinterpret_cast<const v8h*>(src);
         f.l = *reinterpret_cast<const v8h*>(src + 2 * PLANE);
     };
+    auto mfma_row = [&](const BFrag& f, int q) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) { const int b = q - ky; if (b >= 0 && b < TN) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, af[2 * ky + 1]), f.h, acc[b], 0, 0, 0); }
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) { const int b = q - ky; if (b >= 0 && b < TN) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, af[2 * ky]), f.l, acc[b], 0, 0, 0); }
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++) { const int b = q - ky; if (b >= 0 && b < TN) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, af[2 * ky]), f.h, acc[b], 0, 0, 0); }
+    };
     // an M block of pure channel padding (O = 203: channels 224..255 of the fourth tile) stages and synchronises but issues no MFMAs
     const bool active = o0 + mb * 32 < p.O;                                  // wave-uniform
-#ifdef SG3_F23_E3
-#define F23_E3 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" ::: "memory");
-#else
-#define F23_E3
-#endif
     auto mfma_chunk = [&](int buf) {
         if (!active) return;
-#if F23_PRIO_MODE == 1
         __builtin_amdgcn_s_setprio(1);
-#elif F23_PRIO_MODE == 3
-        __builtin_amdgcn_s_setprio(0);
-#endif
         BFrag b0, b1;
         load_b(b0, buf, 0);
-        // patch rows two at a time: the next row's fragments are requested before the current row's nine products are issued
-#define F23_ROWPAIR(Q) \
-        if constexpr ((Q) < TN + 2) { \
-            if constexpr ((Q) + 1 < TN + 2) load_b(b1, buf, (Q) + 1); \
-            __builtin_amdgcn_sched_barrier(0); \
-            F23_E3 \
-            f23_mfma_row<TN, (Q)>(b0.h, b0.l); \
-            __builtin_amdgcn_sched_barrier(0); \
-            if constexpr ((Q) + 1 < TN + 2) { \
-                if constexpr ((Q) + 2 < TN + 2) load_b(b0, buf, (Q) + 2); \
-                __builtin_amdgcn_sched_barrier(0); \
-                F23_E3 \
-                f23_mfma_row<TN, (Q) + 1>(b1.h, b1.l); \
-                __builtin_amdgcn_sched_barrier(0); \
-            } \
+#pragma unroll
+        for (int q = 0; q < TN + 2; q += 2) {
+            if (q + 1 < TN + 2) load_b(b1, buf, q + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_row(b0, q);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < TN + 2) {
+                if (q + 2 < TN + 2) load_b(b0, buf, q + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_row(b1, q + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        F23_ROWPAIR(0) F23_ROWPAIR(2) F23_ROWPAIR(4) F23_ROWPAIR(6) F23_ROWPAIR(8)
-#undef F23_ROWPAIR
-#ifdef SG3_F23_E1
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#endif
-        static_assert(TN + 2 <= 10, "row pairs spelled out for up to ten patch rows");
-#if F23_PRIO_MODE == 1
         __builtin_amdgcn_s_setprio(0);
-#elif F23_PRIO_MODE == 3
-        __builtin_amdgcn_s_setprio(1);
-#endif
     };
 
-    // Chunk body: MFMA loop on chunk ch (B image buf = ch & 1, fragments a[0:23]) and the staging block
-    //   H(k, j) = wait B(k) | stage(k) into the other image | request B(k+1) | land A(j) | request A(j+1)
-    //   waves 0-3 ("early"):  MFMA(ch) | H(ch+1, ch+1) | barrier        -- lands what the NEXT iteration multiplies with
-    //   waves 4-7 ("late"):   H(ch+1, ch) | MFMA(ch) | barrier          -- lands what THIS iteration multiplies with
-    // so on every SIMD one wave's staging arithmetic runs beside the other's matrix instructions, and every request (A: 6 loads,
-    // B: 17) is a whole iteration old when it is waited for.  Load queue, oldest first, when an iteration starts:
-    // early B(ch+1), A(ch+1);  late B(ch+1), A(ch).  Inside H: wait B with 6 younger loads (the A request), land A with 17 (the B
-    // request just issued).  Only the late waves' very first wait finds a different queue (the common prologue leaves B(1) alone
-    // behind it): an extra operand-less s_waitcnt makes it exact.
+    // Chunk body: MFMA loop on chunk ch (B image buf = ch & 1, fragments af) and staging of chunk ch + 1 into the other image.
+    //   waves 0-3 ("early"):  wait A(ch) | MFMA(ch) | request A(ch+1) | wait B(ch+1) | stage(ch+1) | request B(ch+2) | barrier
+    //   waves 4-7 ("late"):   wait B(ch+1) | stage(ch+1) | request B(ch+2) | wait A(ch) | MFMA(ch) | request A(ch+1) | barrier
+    // so on every SIMD one wave's staging arithmetic runs beside the other's matrix instructions.  The fragments of chunk ch + 1 go
+    // into the registers chunk ch has just released: a staging block (the wave's own, in either order) lies between the request and
+    // the first use, which hides the L2 latency without a second register set.
+    // Load queue (oldest first) when an iteration starts -- early: A(ch), B(ch+1);  late: B(ch+1), A(ch).
     const bool late = wave >= 4;                                             // wave-uniform: second wave of its SIMD
     const int nch = p.nch;
-#if F23_PRIO_MODE == 2
-    if (late) __builtin_amdgcn_s_setprio(1);
-#elif F23_PRIO_MODE == 3
-    __builtin_amdgcn_s_setprio(1);
-#endif
-    fetch_a(0);
+    if (!late) fetch_a(0);
     fetch_b(0);
-    F23_WAIT_B(0);                                                           // everything, A(0) included
+    F23_WAIT_B(0);
     stage(0);
     fetch_b(1);
-    if (!late) { F23_LAND(17); fetch_a(1); }                                 // the late waves land A(0) in their first H
+    if (late) fetch_a(0);
     __syncthreads();
 #ifdef SG3_F23_STAMPS
     unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, sPre = 0, sMfma = 0, sPost = 0, sBar = 0, tStart, rStart;
-    unsigned long long h1 = 0, h2 = 0, h3 = 0, h4 = 0, sH[5] = {0, 0, 0, 0, 0};
     F23_STAMP(tStart);
     rStart = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -431,54 +304,52 @@ modconv_f23_kernel(F23Params p) {
         F23_STAMP(tA);
         // ONE MFMA site in the loop (the accumulators must not become a phi of two branches: hipcc then keeps two copies of them)
         if (late) {
-            if (ch == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            F23_WAIT_B(6);
-            F23_STAMP(h1);
+            F23_WAIT_B(6);                                                   // younger: A(ch)
             if (more1) stage(buf ^ 1);
-            F23_STAMP(h2);
             fetch_b(ch + 2);
-            F23_STAMP(h3);
-            F23_LAND(17);
-            F23_STAMP(h4);
-            fetch_a(ch + 1);
         }
+        F23_WAIT_A(17);                                                      // younger: B(ch+1) (early) / B(ch+2) (late)
+#ifdef SG3_F23_DUMPA
+        if (blockIdx.x == 0) {                                               // diagnostic: what the fragments hold after the wait
+            unsigned* o = reinterpret_cast<unsigned*>(p.stamps) + 4096 + ((((size_t)ch * 8 + wave) * 6) * 64 + lane) * 4;
+#pragma unroll
+            for (int f = 0; f < 6; f++) { o[f * 256 + 0] = af[f].x; o[f * 256 + 1] = af[f].y; o[f * 256 + 2] = af[f].z; o[f * 256 + 3] = af[f].w; }
+        }
+#endif
         F23_STAMP(tB);
         mfma_chunk(buf);
         F23_STAMP(tC);
+#ifdef SG3_F23_DRAIN_MFMA
+        {   // experiment: no fragment request before the matrix pipe has executed this chunk's last instruction
+            float t = acc[TN - 1][15];
+            asm volatile("v_mov_b32 %0, %0" : "+v"(t));
+            acc[TN - 1][15] = t;
+        }
+#endif
+        fetch_a(ch + 1);
         if (!late) {
-            F23_WAIT_B(6);
-            F23_STAMP(h1);
+            F23_WAIT_B(6);                                                   // younger: A(ch+1)
             if (more1) stage(buf ^ 1);
-            F23_STAMP(h2);
             fetch_b(ch + 2);
-            F23_STAMP(h3);
-            F23_LAND(17);
-            F23_STAMP(h4);
-            fetch_a(ch + 2);
         }
         F23_STAMP(tD);
         __syncthreads();
 #ifdef SG3_F23_STAMPS
         F23_STAMP(tE);
         sPre += tB - tA; sMfma += tC - tB; sPost += tD - tC; sBar += tE - tD;
-        { const unsigned long long h0 = late ? tA : tC, hE = late ? tB : tD;
-          sH[0] += h1 - h0; sH[1] += h2 - h1; sH[2] += h3 - h2; sH[3] += h4 - h3; sH[4] += hE - h4; }
 #endif
     }
-    // The last requests (beyond the last chunk) are never consumed, but the destination registers of the input samples stay RESERVED
-    // until they have landed: the wait names them.  (An operand-less s_waitcnt here let hipcc reuse them for the epilogue's addresses
-    // before the wait, and the returning zeros overwrote those.)  The matrix instructions were issued from asm statements: the
-    // compiler does not know their latency, so the accumulators are given the wait states an XDL result needs before they are read.
+    // The last requests (beyond the last chunk) are never consumed, but their destination registers stay RESERVED until they have
+    // landed: the waits name them.  (An operand-less s_waitcnt here let hipcc reuse v64 / v68 for the epilogue's addresses before the
+    // wait, and the returning zeros overwrote them -- wrong stores from whichever waves lost that race.)
     F23_WAIT_B(0);
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    F23_WAIT_A(0);
 #ifdef SG3_F23_STAMPS
     if (p.stamps && lane == 0) {
         unsigned long long tEnd; F23_STAMP(tEnd);
         const unsigned long long rEnd = __builtin_amdgcn_s_memrealtime();
         unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
         o[0] = sPre; o[1] = sMfma; o[2] = sPost; o[3] = sBar; o[4] = tEnd - tStart; o[5] = rEnd - rStart;
-        unsigned long long* o2 = p.stamps + (1u << 22) + ((size_t)blockIdx.x * 8 + wave) * 8;      // second half of the buffer: the staging block's parts
-        for (int k = 0; k < 5; k++) o2[k] = sH[k];
     }
 #endif
 
@@ -497,13 +368,11 @@ modconv_f23_kernel(F23Params p) {
         (void*)(p.out + (size_t)n * p.O * p.outH * p.outPitch), (short)0, (int)((unsigned)p.O * planeB), 0x00020000);
     const int gx = x0 + 2 * pq;
     const unsigned colOff = gx < p.outW ? (unsigned)oc * planeB + (unsigned)gx * 4u : 0x80000000u;
-    auto finish_row = [&](auto bc) {
-        constexpr int b = decltype(bc)::value;
-        float accv[16];
-        F23Seq<48 + 16 * b, 16>::read(accv);
+#pragma unroll
+    for (int b = 0; b < TN; b++) {
         float* Xb = X + (b & 1) * (8 * 16 * 64);
 #pragma unroll
-        for (int r = 0; r < 16; r++) Xb[(wave * 16 + r) * 64 + lane] = accv[r];
+        for (int r = 0; r < 16; r++) Xb[(wave * 16 + r) * 64 + lane] = acc[b][r];
         __syncthreads();
         const int gy = y0 + rg * TN + b;
         const unsigned rowOff = gy < p.outH ? colOff + (unsigned)(gy * p.outPitch) * 4u : 0x80000000u;
@@ -516,14 +385,7 @@ modconv_f23_kernel(F23Params p) {
             const u32x2 v = {__builtin_bit_cast(unsigned, ya), __builtin_bit_cast(unsigned, yb)};
             __builtin_amdgcn_raw_buffer_store_b64(v, orr, (int)(rowOff + (unsigned)j * planeB), 0, 0);
         }
-    };
-    finish_row(std::integral_constant<int, 0>{}); finish_row(std::integral_constant<int, 1>{});
-    finish_row(std::integral_constant<int, 2>{}); finish_row(std::integral_constant<int, 3>{});
-    if constexpr (TN > 4) finish_row(std::integral_constant<int, (TN > 4 ? 4 : 0)>{});
-    if constexpr (TN > 5) finish_row(std::integral_constant<int, (TN > 5 ? 5 : 0)>{});
-    if constexpr (TN > 6) finish_row(std::integral_constant<int, (TN > 6 ? 6 : 0)>{});
-    __syncthreads();                                        // the next tile's first staging block writes where this exchange was read
-    }   // tiles of this workgroup
+    }
 }
 
 int64_t f23_packed_floats(int O, int I) {
@@ -563,13 +425,7 @@ static int launch_f23(const sg3_modconv_params& q, hipStream_t st) {
 #endif
     auto kern = modconv_f23_kernel<TN>;
     SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-    static const int cus = [] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
-#ifdef SG3_F23_ONE_TILE
-    const unsigned grid = (unsigned)total;
-#else
-    const unsigned grid = (unsigned)std::min<long long>(total, cus);       // one resident workgroup per CU walks the tiles
-#endif
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ldsBytes, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), ldsBytes, st, p);
     SG3_LAUNCH_CHECK("modconv_f23_kernel");
     return SG3_OK;
 }

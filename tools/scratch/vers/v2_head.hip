@@ -119,12 +119,6 @@ modconv_f23_kernel(F23Params p) {
             const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
             tFirst = start + (b >> 3); tEnd = start + q + (xcd < r ? 1 : 0); tStep = slots;
         } else { tFirst = b; tEnd = nb; tStep = G; }
-#ifdef SG3_F23_ONE_TILE
-        {   // experiment: one tile per workgroup, grid = tiles (XCD-aware order as before)
-            const int q = nb >> 3, r = nb & 7, xcd = b & 7, k = b >> 3;
-            tFirst = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k; tEnd = tFirst + 1; tStep = 1;
-        }
-#endif
     }
     for (int tile = tFirst; tile < tEnd; tile += tStep) {
     int bid = tile;
@@ -160,11 +154,7 @@ modconv_f23_kernel(F23Params p) {
         g0 = rowOk && (unsigned)gx < (unsigned)p.W ? (unsigned)(gy * p.W + gx) * 4u : 0x80000000u;
         // every sample is requested ONCE: a thread loads its own column pair; the pair to its right arrives from the next lane
         // through DPP, and only the last pair of a tile row (lane 15 of its 16) requests the two halo columns itself
-#ifdef SG3_F23_NO_DPP
-        g1 = rowOk && (unsigned)(gx + 2) < (unsigned)p.W ? (unsigned)(gy * p.W + gx + 2) * 4u : 0x80000000u;
-#else
         g1 = rowOk && spair == 15 && (unsigned)(gx + 2) < (unsigned)p.W ? (unsigned)(gy * p.W + gx + 2) * 4u : 0x80000000u;
-#endif
     }
     const unsigned gS = (unsigned)(lane & 15) * 4u;                   // style scales: lane c requests channel c of the chunk
     const int sL = srow * 256 + spair * 16 + sch * PLANE;             // + (xi * 2 + part) * 2 * PLANE
@@ -198,31 +188,19 @@ modconv_f23_kernel(F23Params p) {
     f32x2 rb[8][2];
     float rsc;
     constexpr int NB = 17, NA = 6;                                    // loads per input request / per fragment request
-#ifdef SG3_F23_WAIT0
-#define F23_CNT(N) "0"
-#else
-#define F23_CNT(N) #N
-#endif
-    // Each request is ONE asm statement that opens with "s_nop 4": hipcc may reload a spilled SGPR with v_readlane right in front
-    // of the statement, and an SGPR written by a VALU instruction needs 5 wait states before a vector-memory instruction reads it
-    // (descriptor or scalar offset) -- the compiler pads that hazard for its own instructions, not for ones inside an asm string.
-    // (Seen with the persistent tile loop, which pushed the kernel into SGPR spills: stale descriptors, wrong samples staged.)
+#define F23_A_CLOB(R) "a" #R
     auto fetch_a = [&](int ch) {
         const unsigned so = aS + (unsigned)ch * CHUNKB;               // wave-uniform
         const unsigned vo = ch < p.nch ? aG : 0x80000000u;            // beyond the last chunk: out of range, answered with zeros
-        asm volatile("s_nop 4\n\t"
-                     "buffer_load_dwordx4 a[24:27], %0, %1, %2 offen\n\t"
-                     "buffer_load_dwordx4 a[28:31], %0, %1, %2 offen offset:1024\n\t"
-                     "buffer_load_dwordx4 a[32:35], %0, %1, %2 offen offset:2048\n\t"
-                     "buffer_load_dwordx4 a[36:39], %0, %1, %3 offen\n\t"
-                     "buffer_load_dwordx4 a[40:43], %0, %1, %3 offen offset:1024\n\t"
-                     "buffer_load_dwordx4 a[44:47], %0, %1, %3 offen offset:2048"
-                     :: "v"(vo), "s"(wd), "s"(so), "s"(so + 3 * FRAG)
-                     : "memory", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39",
-                       "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+        asm volatile("buffer_load_dwordx4 a[24:27], %0, %1, %2 offen" :: "v"(vo), "s"(wd), "s"(so) : "memory", "a24", "a25", "a26", "a27");
+        asm volatile("buffer_load_dwordx4 a[28:31], %0, %1, %2 offen" :: "v"(vo), "s"(wd), "s"(so + 1 * FRAG) : "memory", "a28", "a29", "a30", "a31");
+        asm volatile("buffer_load_dwordx4 a[32:35], %0, %1, %2 offen" :: "v"(vo), "s"(wd), "s"(so + 2 * FRAG) : "memory", "a32", "a33", "a34", "a35");
+        asm volatile("buffer_load_dwordx4 a[36:39], %0, %1, %2 offen" :: "v"(vo), "s"(wd), "s"(so + 3 * FRAG) : "memory", "a36", "a37", "a38", "a39");
+        asm volatile("buffer_load_dwordx4 a[40:43], %0, %1, %2 offen" :: "v"(vo), "s"(wd), "s"(so + 4 * FRAG) : "memory", "a40", "a41", "a42", "a43");
+        asm volatile("buffer_load_dwordx4 a[44:47], %0, %1, %2 offen" :: "v"(vo), "s"(wd), "s"(so + 5 * FRAG) : "memory", "a44", "a45", "a46", "a47");
     };
     // wait until all but the N youngest loads have landed, then landing buffer -> current fragments
-#define F23_LAND(N) asm volatile("s_waitcnt vmcnt(" F23_CNT(N) ")\n\t" \
+#define F23_LAND(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\t" \
         "v_accvgpr_mov_b32 a0, a24\n\tv_accvgpr_mov_b32 a1, a25\n\tv_accvgpr_mov_b32 a2, a26\n\tv_accvgpr_mov_b32 a3, a27\n\t" \
         "v_accvgpr_mov_b32 a4, a28\n\tv_accvgpr_mov_b32 a5, a29\n\tv_accvgpr_mov_b32 a6, a30\n\tv_accvgpr_mov_b32 a7, a31\n\t" \
         "v_accvgpr_mov_b32 a8, a32\n\tv_accvgpr_mov_b32 a9, a33\n\tv_accvgpr_mov_b32 a10, a34\n\tv_accvgpr_mov_b32 a11, a35\n\t" \
@@ -248,39 +226,23 @@ modconv_f23_kernel(F23Params p) {
             rb[c][1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)v1, (int)coff, 0));
         }
 #else
-        unsigned cf[8];
+        asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(rsc) : "v"(vs), "s"(sd) : "memory");
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             const int ci = ch * 16 + sch * 8 + c;                       // wave-uniform
-            cf[c] = ci < p.I ? (unsigned)ci * HWb : 0u;                 // padded channels alias channel 0 and meet a zero scale
+            const unsigned coff = ci < p.I ? (unsigned)ci * HWb : 0u;   // padded channels alias channel 0 and meet a zero scale
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(rb[c][0]) : "v"(v0), "s"(xd), "s"(coff) : "memory");
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(rb[c][1]) : "v"(v1), "s"(xd), "s"(coff) : "memory");
         }
-        asm volatile("s_nop 4\n\t"
-                     "buffer_load_dword %0, %9, %10, 0 offen\n\t"
-                     "buffer_load_dwordx2 %1, %11, %13, %14 offen\n\t"
-                     "buffer_load_dwordx2 %2, %12, %13, %14 offen\n\t"
-                     "buffer_load_dwordx2 %3, %11, %13, %15 offen\n\t"
-                     "buffer_load_dwordx2 %4, %12, %13, %15 offen\n\t"
-                     "buffer_load_dwordx2 %5, %11, %13, %16 offen\n\t"
-                     "buffer_load_dwordx2 %6, %12, %13, %16 offen\n\t"
-                     "buffer_load_dwordx2 %7, %11, %13, %17 offen\n\t"
-                     "buffer_load_dwordx2 %8, %12, %13, %17 offen"
-                     : "=&v"(rsc), "=&v"(rb[0][0]), "=&v"(rb[0][1]), "=&v"(rb[1][0]), "=&v"(rb[1][1]), "=&v"(rb[2][0]), "=&v"(rb[2][1]), "=&v"(rb[3][0]), "=&v"(rb[3][1])
-                     : "v"(vs), "s"(sd), "v"(v0), "v"(v1), "s"(xd), "s"(cf[0]), "s"(cf[1]), "s"(cf[2]), "s"(cf[3]) : "memory");
-        asm volatile("s_nop 4\n\t"
-                     "buffer_load_dwordx2 %0, %8, %10, %11 offen\n\t"
-                     "buffer_load_dwordx2 %1, %9, %10, %11 offen\n\t"
-                     "buffer_load_dwordx2 %2, %8, %10, %12 offen\n\t"
-                     "buffer_load_dwordx2 %3, %9, %10, %12 offen\n\t"
-                     "buffer_load_dwordx2 %4, %8, %10, %13 offen\n\t"
-                     "buffer_load_dwordx2 %5, %9, %10, %13 offen\n\t"
-                     "buffer_load_dwordx2 %6, %8, %10, %14 offen\n\t"
-                     "buffer_load_dwordx2 %7, %9, %10, %14 offen"
-                     : "=&v"(rb[4][0]), "=&v"(rb[4][1]), "=&v"(rb[5][0]), "=&v"(rb[5][1]), "=&v"(rb[6][0]), "=&v"(rb[6][1]), "=&v"(rb[7][0]), "=&v"(rb[7][1])
-                     : "v"(v0), "v"(v1), "s"(xd), "s"(cf[4]), "s"(cf[5]), "s"(cf[6]), "s"(cf[7]) : "memory");
 #endif
     };
     // AUDIT after every edit (tools/audit_f23_asm.py on the -save-temps .s): between a hand-issued load and the wait that covers it
     // hipcc must not read or copy the destination registers (it treats them as written when the load is issued).
+#ifdef SG3_F23_WAIT0
+#define F23_CNT(N) "0"
+#else
+#define F23_CNT(N) #N
+#endif
 #if defined(SG3_F23_BUILTIN) || defined(SG3_F23_BUILTIN_B)
 #define F23_WAIT_B(N) do { } while (0)
 #else
@@ -308,10 +270,8 @@ modconv_f23_kernel(F23Params p) {
             // columns (2p+2, 2p+3) = the own pair of the lane to the right (row_shl: lane i takes lane i + 1 of its row of 16; the
             // last lane of a row has no source and keeps what it loaded: the halo pair)
             float nx = rb[c][1].x, ny = rb[c][1].y;
-#ifndef SG3_F23_NO_DPP
             asm("v_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(nx) : "v"(rb[c][0].x));
             asm("v_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(ny) : "v"(rb[c][0].y));
-#endif
             const f32x2 right = {nx, ny};
             f32x2 t;
             asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(right), "s"(sc2));
@@ -353,11 +313,6 @@ modconv_f23_kernel(F23Params p) {
     };
     // an M block of pure channel padding (O = 203: channels 224..255 of the fourth tile) stages and synchronises but issues no MFMAs
     const bool active = o0 + mb * 32 < p.O;                                  // wave-uniform
-#ifdef SG3_F23_E3
-#define F23_E3 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" ::: "memory");
-#else
-#define F23_E3
-#endif
     auto mfma_chunk = [&](int buf) {
         if (!active) return;
 #if F23_PRIO_MODE == 1
@@ -372,22 +327,17 @@ modconv_f23_kernel(F23Params p) {
         if constexpr ((Q) < TN + 2) { \
             if constexpr ((Q) + 1 < TN + 2) load_b(b1, buf, (Q) + 1); \
             __builtin_amdgcn_sched_barrier(0); \
-            F23_E3 \
             f23_mfma_row<TN, (Q)>(b0.h, b0.l); \
             __builtin_amdgcn_sched_barrier(0); \
             if constexpr ((Q) + 1 < TN + 2) { \
                 if constexpr ((Q) + 2 < TN + 2) load_b(b0, buf, (Q) + 2); \
                 __builtin_amdgcn_sched_barrier(0); \
-                F23_E3 \
                 f23_mfma_row<TN, (Q) + 1>(b1.h, b1.l); \
                 __builtin_amdgcn_sched_barrier(0); \
             } \
         }
         F23_ROWPAIR(0) F23_ROWPAIR(2) F23_ROWPAIR(4) F23_ROWPAIR(6) F23_ROWPAIR(8)
 #undef F23_ROWPAIR
-#ifdef SG3_F23_E1
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#endif
         static_assert(TN + 2 <= 10, "row pairs spelled out for up to ten patch rows");
 #if F23_PRIO_MODE == 1
         __builtin_amdgcn_s_setprio(0);
@@ -564,11 +514,7 @@ static int launch_f23(const sg3_modconv_params& q, hipStream_t st) {
     auto kern = modconv_f23_kernel<TN>;
     SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
     static const int cus = [] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
-#ifdef SG3_F23_ONE_TILE
-    const unsigned grid = (unsigned)total;
-#else
     const unsigned grid = (unsigned)std::min<long long>(total, cus);       // one resident workgroup per CU walks the tiles
-#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ldsBytes, st, p);
     SG3_LAUNCH_CHECK("modconv_f23_kernel");
     return SG3_OK;
