@@ -495,6 +495,12 @@ def main(argv=None):
         torch.cuda.synchronize()
         timer.enabled = False
     assert tuple(img.shape) == (args.batch, 3, G.img_resolution, G.img_resolution) and bool(torch.isfinite(img).all())
+    # per step: the 14 streaming filtered_lrelu launches; 16 convolution launches (the channel mix of the Fourier-feature input runs on
+    # the 1x1 kernel too).  Read here: the inversion / PTI legs below reuse (and reset) the timer for their own roofline objects
+    total_bytes, fl_layers = flrelu_algorithmic_bytes(G, args.batch)
+    fl_ms = timer.median_step_ms('filtered_lrelu', len(fl_layers))
+    conv_ms = timer.median_step_ms('modulated_conv2d', len(G.synthesis.layer_names) + 1)
+    timer.reset()
 
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
@@ -515,11 +521,6 @@ def main(argv=None):
         extras = bench_extras(G, ws, device, timer=timer)
 
     if rank == 0:
-        n_layers = len(G.synthesis.layer_names)
-        total_bytes, fl_layers = flrelu_algorithmic_bytes(G, args.batch)
-        fl_ms = timer.median_step_ms('filtered_lrelu', len(fl_layers))    # per step: the 14 streaming launches
-        # 16 convolution launches per step: the channel mix of the Fourier-feature input runs on the 1x1 kernel too
-        conv_ms = timer.median_step_ms('modulated_conv2d', n_layers + 1)
         achieved = total_bytes / (fl_ms * 1e-3) / 1e9 if fl_ms > 0 else 0.0
         # HBM traffic of the same 14 launches from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes over this
         # command, summarised by tools/sum_traffic.py, which stamps the kernel source it ran on); only valid for the default workload

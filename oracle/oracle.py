@@ -381,18 +381,47 @@ def layer_styles(sd, layer, w):
     return s
 
 
-def synthesis_layer(sd, layer, x, styles):
-    """networks_stylegan3.py:335-368 (fp32 path, update_emas=False)."""
+def _f16(a):
+    """Round to float16 and back (the value a float16 tensor holds)."""
+    return np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+def modulated_conv2d_fp16(x, w, s, demodulate=True, padding=0, input_gain=None):
+    """networks_stylegan3.py:24-63 as the reference executes it for a `use_fp16` layer on a GPU (x.dtype == float16, :355-357):
+    the per-sample weights are formed in fp32 (:39-56) and cast to the activation dtype (:61 `w.to(x.dtype)`), the grouped
+    convolution multiplies fp16 operands, accumulates in fp32 and returns fp16.  NOT pinned by a reference fixture (the reference's
+    fp16 path needs a GPU): a restatement of its rounding points, used as an independent yardstick for the HIP fp16 path."""
+    x = _f16(x); w = np.asarray(w, dtype=np.float32); s = np.asarray(s, dtype=np.float32)
+    n = x.shape[0]
+    if demodulate:
+        w = w * (np.float32(1) / np.sqrt(np.mean(np.square(w), axis=(1, 2, 3), keepdims=True)))
+        s = s * (np.float32(1) / np.sqrt(np.mean(np.square(s))))
+    we = w[None] * s[:, None, :, None, None]                                         # [N,O,I,k,k]
+    if demodulate:
+        we = we * (np.float32(1) / np.sqrt(np.sum(np.square(we), axis=(2, 3, 4), keepdims=True) + np.float32(1e-8)))
+    if input_gain is not None:
+        we = we * np.float32(input_gain)
+    we = _f16(we)
+    y = np.concatenate([conv2d(np.ascontiguousarray(x[i:i + 1]), np.ascontiguousarray(we[i]), None, 1, padding) for i in range(n)], axis=0)
+    return _f16(y)
+
+
+def synthesis_layer(sd, layer, x, styles, fp16=False):
+    """networks_stylegan3.py:335-368 (update_emas=False).  `fp16`: the layer runs as the reference runs a `use_fp16` layer on a GPU
+    without force_fp32 (:355-366): fp16 activations and convolution operands, fp32 arithmetic inside filtered_lrelu, fp16 output."""
     p = f"synthesis.{layer['name']}."
     input_gain = 1.0 / np.sqrt(np.float32(sd[p + 'magnitude_ema']))
-    x = modulated_conv2d(x, sd[p + 'weight'], styles, demodulate=not layer['is_torgb'],
-                         padding=layer['conv_kernel'] - 1, input_gain=input_gain)
+    conv = modulated_conv2d_fp16 if fp16 else modulated_conv2d
+    x = conv(x, sd[p + 'weight'], styles, demodulate=not layer['is_torgb'],
+             padding=layer['conv_kernel'] - 1, input_gain=input_gain)
     gain = 1.0 if layer['is_torgb'] else np.sqrt(2)
     slope = 1.0 if layer['is_torgb'] else 0.2
     fu = sd.get(p + 'up_filter')
     fd = sd.get(p + 'down_filter')
-    return filtered_lrelu(x, fu=fu, fd=fd, b=sd[p + 'bias'].astype(x.dtype), up=layer['up'], down=layer['down'],
-                          padding=layer['padding'], gain=gain, slope=slope, clamp=layer['conv_clamp'])
+    b = sd[p + 'bias'].astype(x.dtype)
+    y = filtered_lrelu(x, fu=fu, fd=fd, b=_f16(b) if fp16 else b, up=layer['up'], down=layer['down'],
+                       padding=layer['padding'], gain=gain, slope=slope, clamp=layer['conv_clamp'])
+    return _f16(y) if fp16 else y
 
 
 def w2s(sd, sched, ws):
@@ -404,21 +433,22 @@ def w2s(sd, sched, ws):
     return out
 
 
-def synthesis(sd, sched, ws=None, all_s=None, transform=None, return_layers=False):
-    """networks_stylegan3.py:471-494: W path or StyleSpace (all_s) path, fp32."""
+def synthesis(sd, sched, ws=None, all_s=None, transform=None, return_layers=False, mixed_fp16=False):
+    """networks_stylegan3.py:471-494: W path or StyleSpace (all_s) path, fp32; `mixed_fp16`: the layers flagged use_fp16 run as on a
+    GPU without force_fp32 (see synthesis_layer)."""
     feats = []
     if all_s is None:
         ws = ws.astype(np.float32)
         assert ws.shape[1:] == (sched['num_ws'], sched['w_dim'])
         x = synthesis_input(sd, sched, w=ws[:, 0], transform=transform)
         for i, layer in enumerate(sched['layers']):
-            x = synthesis_layer(sd, layer, x, layer_styles(sd, layer, ws[:, i + 1]))
+            x = synthesis_layer(sd, layer, x, layer_styles(sd, layer, ws[:, i + 1]), fp16=mixed_fp16 and layer['use_fp16'])
             if return_layers:
                 feats.append(x)
     else:
         x = synthesis_input(sd, sched, t=all_s['input'], transform=transform)
         for layer in sched['layers']:
-            x = synthesis_layer(sd, layer, x, all_s[layer['name']].astype(np.float32))
+            x = synthesis_layer(sd, layer, x, all_s[layer['name']].astype(np.float32), fp16=mixed_fp16 and layer['use_fp16'])
             if return_layers:
                 feats.append(x)
     if sched['output_scale'] != 1:

@@ -244,5 +244,6 @@ def test_run_on_batch_survives_weight_updates_after_graph_capture():
         sh = ShardedInversion(net, opts, batch_size=3)
         assert net.graphed_step is not None and not net.graphed_step.is_stale()        # re-captured on the new weights
         lat, (a, b) = sh.invert(x.cpu())
+        eager = run_on_batch(x, net, opts, sh.avg_image)                                   # the average image of the NEW weights
     assert (a, b) == (0, 3) and lat.is_cuda
     assert maxabs(lat.cpu().numpy(), np.stack([eager[1][i][2] for i in range(3)])) <= 1e-5 * max(1.0, float(np.abs(eager[1][0][2]).max()))

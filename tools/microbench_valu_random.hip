@@ -9,6 +9,15 @@
 //           one LDS row hand-off + 12-tap H-down per trip; taps in scalar registers; no global traffic in the loop
 //   mode 3  mode 2 + the kernel's HBM stream: per row every lane loads 2 dwords (prefetched three rows ahead) and stores one
 //           8-byte pair, each wave walking its own region of a 4 GiB buffer (8 B in + 8 B out per lane and row, like an up-2 layer)
+//   mode 4  mode 3 with the V-down scatter (24 of the 76 packed ops of a row) moved to the matrix pipe as banded fp32 MFMA
+//           blocks, v_mfma_f32_16x16x4_f32: 16 output rows x 16 columns x 4 input rows per instruction; a 12-tap stride-2 band
+//           fills 12 of every 44 input rows of a 16-row block, so a row of 256 columns costs 11 instructions (32 matrix-pipe
+//           cycles each).  Operands are taken from the registers as they lie (the real kernel would first have to move the
+//           input rows across lane groups): an UPPER bound for the MFMA variant
+//           (64 accumulator registers for the 16 rows in flight: 192 registers, 2 waves/SIMD; mode 6 = the same held to 128
+//           registers for 4 waves/SIMD, which spills)
+//   mode 5  the same with v_mfma_f32_4x4x1_16B_f32: 16 blocks of 4 output rows x 4 columns x 1 input row, whose B / D layout IS
+//           the kernel's (lane = column): 18 instructions of 8 matrix-pipe cycles per row, no relayout needed
 // Build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/microbench_valu_random.hip -o /tmp/mv && /tmp/mv
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -30,7 +39,7 @@ __device__ __forceinline__ float rnd(unsigned i) {
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(256) k(float* out, unsigned long long* stamps, int iters, Taps tp, const float* gin, float* gout, unsigned gmask) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE >= 5 ? 4 : 1, 8))) k(float* out, unsigned long long* stamps, int iters, Taps tp, const float* gin, float* gout, unsigned gmask) {
     __shared__ __attribute__((aligned(16))) float sm[4 * 1024 + 4 * 512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     lds_f* tab = (lds_f*)sm + wave * 1024;          // this wave's random table
@@ -39,6 +48,16 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* stamps,
     for (int i = lane; i < 512; i += 64) row[i] = 0.f;
     __syncthreads();
     v2f x[8], acc[12];
+    constexpr bool M16 = MODE == 4 || MODE == 6;
+    constexpr int NT = M16 ? 16 : 12, NM = M16 ? 11 : 18;       // accumulator tiles in flight, MFMAs per row
+    v4f macc[NT];
+    float band[4];
+    if (MODE >= 4) {
+#pragma unroll
+        for (int i = 0; i < NT; i++) macc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; i++) band[i] = rnd(threadIdx.x * 32 + i) * 0.6f;      // the band's coefficients, one A operand per lane
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++) { x[i] = (v2f){rnd(threadIdx.x * 16 + 2 * i + blockIdx.x * 7919), rnd(threadIdx.x * 16 + 2 * i + 1 + blockIdx.x * 104729)}; acc[i] = MODE == 0 ? x[i] + splat((float)i) : splat(0.f); }
 #pragma unroll
@@ -65,7 +84,7 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* stamps,
         const unsigned wid = (blockIdx.x * 4 + wave);
         unsigned gpos = wid * (unsigned)(iters * 6 * 128);
         float pre[3][2];
-        if (MODE == 3) {
+        if (MODE >= 3) {
 #pragma unroll
             for (int r = 0; r < 3; r++) { pre[r][0] = gin[((gpos + r * 128) & gmask) + lane]; pre[r][1] = gin[((gpos + r * 128) & gmask) + 64 + lane]; }
         }
@@ -73,7 +92,7 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* stamps,
 #pragma unroll
             for (int S = 0; S < 6; S++) {             // six rows per trip, window slots resolved at compile time
                 const int base = ((it * 6 + S) * 16 + 2 * lane) & 1015;
-                if (MODE == 3) {
+                if (MODE >= 3) {
                     // the staged input row goes through LDS like the kernel's (two dword writes), next row requested
                     tab[(base + 512) & 1023] = pre[S % 3][0]; tab[(base + 640) & 1023] = pre[S % 3][1];
                     const unsigned nxt = (gpos + 3 * 128) & gmask;
@@ -100,6 +119,14 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* stamps,
 #pragma unroll
                     for (int c = 0; c < 4; c++) a[c] = __builtin_amdgcn_fmed3f(a[c], -181.f, 181.f);
                     const v2f r0v = {a[0], a[1]}, r1v = {a[2], a[3]};
+                    if (MODE >= 4) {
+#pragma unroll
+                        for (int m = j * (NM / 2 + NM % 2); m < (j == 0 ? NM / 2 + NM % 2 : NM); m++) {
+                            const int tile = (S * NM + m) % NT;
+                            if (M16) macc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(band[m & 3], a[m & 3], macc[tile], 0, 0, 0);
+                            else macc[tile] = __builtin_amdgcn_mfma_f32_4x4x1f32(band[m & 3], a[m & 3], macc[tile], 0, 0, 0);
+                        }
+                    } else
 #pragma unroll
                     for (int r = 0; r < 6; r++) {
                         const int slot = (S + 5 - r) % 6;          // six output rows in flight, as in the kernel
@@ -109,7 +136,9 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* stamps,
                 }
                 // completed output row: hand-off through LDS, 12-tap H-down, result folded back into the oldest accumulator
                 const int slot = S % 6;
-                *reinterpret_cast<volatile lds_v4f*>(row + 4 + 4 * lane) = (v4f){acc[2 * slot].x, acc[2 * slot].y, acc[2 * slot + 1].x, acc[2 * slot + 1].y};
+                const int mt = (S * NM) % NT;                       // the accumulator tile that "completes" with this row (modes 4 / 5)
+                if (MODE >= 4) *reinterpret_cast<volatile lds_v4f*>(row + 4 + 4 * lane) = macc[mt];
+                else *reinterpret_cast<volatile lds_v4f*>(row + 4 + 4 * lane) = (v4f){acc[2 * slot].x, acc[2 * slot].y, acc[2 * slot + 1].x, acc[2 * slot + 1].y};
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 v2f pr[8];
 #pragma unroll
@@ -117,9 +146,12 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* stamps,
                 v2f y0 = pr[0] * (v2f){tp.t[0], tp.t[1]}, y1 = pr[1] * (v2f){tp.t[0], tp.t[1]};
 #pragma unroll
                 for (int q = 1; q < 6; q++) { y0 = fma2(pr[q], (v2f){tp.t[2 * q], tp.t[2 * q + 1]}, y0); y1 = fma2(pr[q + 1], (v2f){tp.t[2 * q], tp.t[2 * q + 1]}, y1); }
-                if (MODE == 3) { *reinterpret_cast<v2f*>(gout + (gpos & gmask) + 2 * lane) = (v2f){y0.x + y0.y, y1.x + y1.y}; gpos += 128; }
-                acc[2 * slot] = (v2f){(y0.x + y0.y) * 0.01f, (y1.x + y1.y) * 0.01f};      // keeps the accumulators bounded
-                acc[2 * slot + 1] = splat(0.f);
+                if (MODE >= 3) { *reinterpret_cast<v2f*>(gout + (gpos & gmask) + 2 * lane) = (v2f){y0.x + y0.y, y1.x + y1.y}; gpos += 128; }
+                if (MODE >= 4) macc[mt] = (v4f){(y0.x + y0.y) * 0.01f, (y1.x + y1.y) * 0.01f, 0.f, 0.f};
+                else {
+                    acc[2 * slot] = (v2f){(y0.x + y0.y) * 0.01f, (y1.x + y1.y) * 0.01f};      // keeps the accumulators bounded
+                    acc[2 * slot + 1] = splat(0.f);
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
@@ -128,6 +160,10 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* stamps,
     float s = 0;
 #pragma unroll
     for (int i = 0; i < 12; i++) s += acc[i].x + acc[i].y;
+    if (MODE >= 4) {
+#pragma unroll
+        for (int i = 0; i < NT; i++) s += macc[i].x + macc[i].y + macc[i].z + macc[i].w;
+    }
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (lane == 0) { stamps[2 * (blockIdx.x * 4 + wave)] = c1 - c0; stamps[2 * (blockIdx.x * 4 + wave) + 1] = r1 - r0; }
 }
@@ -176,6 +212,10 @@ int main() {
         // packed-FMA-class instructions per trip (6 rows): H-up 12, V-up 24, slope mul 2 x 2, V-down 24, H-down 12 -> 76 per row
         run<2>("flrelu up-2 row arithmetic + LDS", bpc, 700, 6 * 76, d, st, rt);
         run<3>("... + HBM stream 8 B in / 8 B out", bpc, 700, 6 * 76, d, st, rt, gin, gout, gmask);
+        // the same 76 packed-op-equivalents of work per row, 24 of them on the matrix pipe: TFLOP/s and "cycles each" stay comparable
+        run<4>("... V-down as 11 mfma_16x16x4_f32", bpc, 700, 6 * 76, d, st, rt, gin, gout, gmask);
+        run<5>("... V-down as 18 mfma_4x4x1_f32", bpc, 700, 6 * 76, d, st, rt, gin, gout, gmask);
+        run<6>("... 11 mfma_16x16x4, 128 regs (spills)", bpc, 700, 6 * 76, d, st, rt, gin, gout, gmask);
     }
     return 0;
 }

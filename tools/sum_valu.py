@@ -3,6 +3,7 @@
     rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE \\
         --output-format csv -d D -o v -- python3 bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline --no-inversion --no-extras
     python tools/sum_valu.py D/v_counter_collection.csv D/v_kernel_trace.csv > profiles/rNN_flrelu_valu_pmc.txt
+    ... -- python3 tools/time_config.py R1024 --batch 8 --iters 2   +   sum_valu.py <csv> <trace> "config R-1024"  for the radial kernels
 
 Units (MI355X_MICROARCH.md, cycle-constants table): SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles summed over
 waves; one VALU instruction holds its SIMD's vector issue for 4 cycles = 1 quad-cycle, so SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU here.
@@ -18,7 +19,8 @@ for r in rows:
 dur = {int(r['Dispatch_Id']): (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in csv.DictReader(open(sys.argv[2]))}
 disp = [(k, v) for k, v in sorted(by.items()) if 'flrelu_stream' in v['name']][-14:]
 assert len(disp) == 14
-print('filtered_lrelu launches of one T-1024 batch-8 forward (profiled pass: clocks read 3-5 % below an un-profiled run)')
+title = sys.argv[3] if len(sys.argv) > 3 else 'T-1024'
+print(f'filtered_lrelu launches of one {title} batch-8 forward (profiled pass: clocks read 3-5 % below an un-profiled run)')
 print(f"{'layer':5s} {'kernel':22s} {'us':>8s} {'GHz':>5s} {'VALU insts M':>13s} {'VALU issue util':>16s} {'waves/SIMD':>11s} {'wait_any':>9s} {'wait_inst':>10s}")
 tv = ta = 0.0
 for j, (k, d) in enumerate(disp):
