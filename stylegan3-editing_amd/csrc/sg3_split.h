@@ -13,6 +13,11 @@ template <> struct bufld<float> {
     static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, (int)soff, 0));
     }
+    // One element kept RAW until the caller converts it (a conversion at the request would wait for the data there).
+    static __device__ __forceinline__ unsigned ldraw(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+        return __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, (int)soff, 0);
+    }
+    static __device__ __forceinline__ float fromraw(unsigned v) { return __builtin_bit_cast(float, v); }
     // Two adjacent elements with one load, kept RAW (raw2) until the caller needs them (unpack2).
     // NOTE: the elements are copied to scalars before __builtin_bit_cast: hipcc 7.2 (clang 22.0.0git roc-7.2.0) compiles
     // __builtin_bit_cast(float, v.y) on an ext-vector element expression as a read of element 0.
@@ -29,6 +34,10 @@ template <> struct bufld<_Float16> {
     static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
         return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, (int)off, (int)soff, 0));
     }
+    static __device__ __forceinline__ unsigned ldraw(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+        return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, (int)off, (int)soff, 0);
+    }
+    static __device__ __forceinline__ float fromraw(unsigned v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)v); }
     typedef unsigned raw2;
     static __device__ __forceinline__ raw2 ld2(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
         return __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, (int)soff, 0);

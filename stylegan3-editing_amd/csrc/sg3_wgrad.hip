@@ -19,12 +19,15 @@
 // read once per K step for 27 MFMAs.  Tiles with fewer than four real 32 x 32 blocks (the thin 1024^2 layers: 32 -> 32 is ONE
 // block, 51 -> 32 two) give the idle waves a share of the TAPS instead of a block of channel padding: two waves per block take
 // 5 + 4 taps, four waves 3 + 2 + 2 + 2 (a wave-uniform range test around each tap's three MFMAs; staging is unchanged).  Per (row, segment): the dy segment and the new xp row segment are split and staged
-// in LDS (the three xp rows a dy row touches live in a ring, so every xp row is staged once per band); the column shift
+// in LDS (the three xp rows a dy row touches live in a ring of four, so every xp row is staged once per band, and the samples of
+// row y + 1 are requested before the MFMAs of row y and handed to LDS after them: one barrier per row); the column shift
 // kx of a tap is taken in registers from a 16-half window (two aligned ds_read_b128): kx = 2 is a register rename, kx = 1
 // four v_alignbyte.  The K dimension is split over workgroups; partial sums go to [split][n][tap][o][i] (coalesced
 // stores) and are reduced by the caller -- deterministic, no float atomics.
 #include "sg3_common.h"
 #include "sg3_split.h"
+#include <type_traits>
+#include <cstdlib>
 
 namespace sg3 {
 
@@ -49,13 +52,15 @@ __global__ void __launch_bounds__(256, 2)
 wgrad_f16x3_kernel(WgradParams p) {
     constexpr int TAPS = KS * KS;
     constexpr int KT = 32;                              // dy pixels per staged segment (two K steps of 16)
+    static_assert(KT == 32, "the row loop issues exactly two K steps");
     constexpr int XW = KT + 16;                         // xp pixels per staged row segment (shift window + alignment)
     constexpr int DP = KT + 8, XP = XW + 8;             // LDS row pitches in halfs (conflict-free b128 rows)
     constexpr int DPLANE = 64 * DP, XPLANE = 64 * XP;   // halfs per (part) plane
-    constexpr int RING = KS;                            // xp rows alive per dy row
+    constexpr int RING = KS + 1;                        // xp rows alive per dy row + the one being staged for the next row
 
-    __shared__ __attribute__((aligned(16))) _Float16 sD[2 * DPLANE];
-    __shared__ __attribute__((aligned(16))) _Float16 sX[RING * 2 * XPLANE];
+    extern __shared__ __attribute__((aligned(16))) _Float16 wgradLds[];
+    _Float16* const sD = wgradLds;                      // [2 buffers][hi | lo][64 rows][DP]
+    _Float16* const sX = wgradLds + 2 * 2 * DPLANE;     // [RING slots][hi | lo][64 rows][XP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -85,64 +90,77 @@ wgrad_f16x3_kernel(WgradParams p) {
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const T*)p.x + (size_t)n * p.I * p.H * p.W), (short)0, (int)((unsigned)p.I * xPlane), 0x00020000);
 
-    // staging maps: thread -> (row of the tile, group of consecutive pixels)
-    const int srow = tid >> 2, sgrp = tid & 3;
-    const bool dOk = o0 + srow < p.O, xOk = i0 + srow < p.I;
-    const unsigned dRowOff = dOk ? (unsigned)(o0 + srow) * dyPlane : 0u;
-    const unsigned xRowOff = xOk ? (unsigned)(i0 + srow) * xPlane : 0u;
-
+    // staging maps.  A request covers whole row pieces with consecutive lanes on consecutive pixels (2 rows x 32 pixels of dy, 4 rows x
+    // 16 pixels of the input: 3 - 6 cache lines per instruction; a thread-owns-8-pixels map touches 16 - 32 lines per instruction and
+    // made the L1 the limiter).  Rows of channel padding lie beyond num_records (= channels x plane) by themselves; an invalid column
+    // starts from the out-of-range sentinel, to which the row term (< 2^31, see the size checks) is added.
+    const int dRow0 = wave * 16 + (lane >> 5), dCol = lane & 31;           // dy: rows dRow0 + 2 j (j < 8), one column
+    const int xRow0 = wave * 16 + (lane >> 4), xCol = lane & 15;           // x : rows xRow0 + 4 (j / 3), columns xCol + 16 (j % 3), j < 12
+    const unsigned dRowOff = (unsigned)(o0 + dRow0) * dyPlane;
+    const unsigned xRowOff = (unsigned)(i0 + xRow0) * xPlane;
     f32x16 acc[TAPS];
 #pragma unroll
     for (int tp = 0; tp < TAPS; tp++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[tp][r] = 0.f;
 
-    // one row segment of dy -> sD; 8 pixels per thread
-    auto stage_dy = [&](int y, int xs) {
-        float v[8];
+    // Staging is split into its request and its hand-over so that the requests of row y + 1 fly during the MFMAs of row y
+    auto load_dy = [&](int y, int xs, unsigned (&v)[8], bool rowOk) {
+        const int px = xs + dCol;
+        const unsigned base = (px < (rowOk ? p.OW : 0) ? (unsigned)(y * p.OW + px) * (unsigned)sizeof(T) : 0x80000000u) + dRowOff;
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int px = xs + sgrp * 8 + e;
-            const unsigned off = (dOk && px < p.OW) ? dRowOff + (unsigned)(y * p.OW + px) * (unsigned)sizeof(T) : 0x80000000u;
-            v[e] = bufld<T>::ld(dr, off, 0) * scD;
-        }
-        v2h h[4], l[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) split2(v[2 * c], v[2 * c + 1], h[c], l[c]);
-        _Float16* dst = sD + srow * DP + sgrp * 8;
-        *reinterpret_cast<v8h*>(dst) = __builtin_shufflevector(__builtin_shufflevector(h[0], h[1], 0, 1, 2, 3), __builtin_shufflevector(h[2], h[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
-        *reinterpret_cast<v8h*>(dst + DPLANE) = __builtin_shufflevector(__builtin_shufflevector(l[0], l[1], 0, 1, 2, 3), __builtin_shufflevector(l[2], l[3], 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
+        for (int j = 0; j < 8; j++) v[j] = bufld<T>::ldraw(dr, base + (unsigned)(2 * j) * dyPlane, 0);
     };
-    // one row segment of the padded input (padded row yp, padded columns xs .. xs + XW - 1) -> ring slot; 12 pixels per thread
-    auto stage_x = [&](int yp, int xs, int slot) {
-        const int gy = yp - p.pad;
-        const bool rowOk = xOk && (unsigned)gy < (unsigned)p.H;
-        float v[12];
+    auto write_dy_pair = [&](const unsigned (&v)[8], int buf, int c) {     // rows dRow0 + 4 c and dRow0 + 4 c + 2
+        _Float16* dst = sD + buf * 2 * DPLANE + dRow0 * DP + dCol;
+        v2h h, l;
+        split2(bufld<T>::fromraw(v[2 * c]) * scD, bufld<T>::fromraw(v[2 * c + 1]) * scD, h, l);
+        dst[(4 * c) * DP] = h.x; dst[(4 * c + 2) * DP] = h.y;
+        dst[DPLANE + (4 * c) * DP] = l.x; dst[DPLANE + (4 * c + 2) * DP] = l.y;
+    };
+    auto write_dy = [&](const unsigned (&v)[8], int buf) {
 #pragma unroll
-        for (int e = 0; e < 12; e++) {
-            const int gx = xs + sgrp * 12 + e - p.pad;
-            const unsigned off = (rowOk && (unsigned)gx < (unsigned)p.W) ? xRowOff + (unsigned)(gy * p.W + gx) * (unsigned)sizeof(T) : 0x80000000u;
-            v[e] = bufld<T>::ld(xr, off, 0) * scX;
-        }
-        _Float16* dst = sX + slot * 2 * XPLANE + srow * XP + sgrp * 12;
+        for (int c = 0; c < 4; c++) write_dy_pair(v, buf, c);
+    };
+    // the padded input: padded row yp, padded columns xs .. xs + XW - 1
+    auto load_x = [&](int yp, int xs, unsigned (&v)[12], bool wanted) {
+        const int gy = yp - p.pad;
+        const bool rowOk = wanted & ((unsigned)gy < (unsigned)p.H);         // uniform; a padding row has no valid column
+        const unsigned wLimit = rowOk ? (unsigned)p.W : 0u;
+        const unsigned rowTerm = xRowOff + (unsigned)((rowOk ? gy : 0) * p.W) * (unsigned)sizeof(T);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            v2h h0, l0, h1, l1;
-            split2(v[4 * c], v[4 * c + 1], h0, l0);
-            split2(v[4 * c + 2], v[4 * c + 3], h1, l1);
-            typedef _Float16 v4h __attribute__((ext_vector_type(4)));
-            *reinterpret_cast<v4h*>(dst + 4 * c) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
-            *reinterpret_cast<v4h*>(dst + XPLANE + 4 * c) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
+            const int gx = xs + xCol + 16 * c - p.pad;
+            const unsigned base = ((unsigned)gx < wLimit ? (unsigned)gx * (unsigned)sizeof(T) : 0x80000000u) + rowTerm;
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[3 * r + c] = bufld<T>::ldraw(xr, base + (unsigned)(4 * r) * xPlane, 0);
         }
     };
-    // (ky, all kx) of one K step: the 16-half window of this lane's input row, then the three column shifts
-    auto taps_of_row = [&](int slot, int ky, int k0, v8h ah, v8h al) {
-        if (ky * KS + KS <= tLo || ky * KS >= tHi) return;                 // none of this filter row's taps is this wave's
+    auto write_x_pair = [&](const unsigned (&v)[12], int slot, int c, int r) {    // column block c, rows xRow0 + 4 r and xRow0 + 4 r + 4
+        _Float16* dst = sX + slot * 2 * XPLANE + xRow0 * XP + xCol;
+        v2h h, l;
+        split2(bufld<T>::fromraw(v[3 * r + c]) * scX, bufld<T>::fromraw(v[3 * (r + 1) + c]) * scX, h, l);
+        dst[(4 * r) * XP + 16 * c] = h.x; dst[(4 * r + 4) * XP + 16 * c] = h.y;
+        dst[XPLANE + (4 * r) * XP + 16 * c] = l.x; dst[XPLANE + (4 * r + 4) * XP + 16 * c] = l.y;
+    };
+    auto write_x = [&](const unsigned (&v)[12], int slot) {
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) write_x_pair(v, slot, c, r);
+    };
+    // (ky, all kx) of one K step: the 16-half window of this lane's input row, then the three column shifts.  RANGE = this wave
+    // owns only taps [tLo, tHi) (thin tiles; wave-uniform tests); without it the nine MFMAs of a filter row are straight-line code,
+    // issued part by part over the three shifts so that neighbours in the matrix pipe never wait for each other's accumulator
+    auto taps_of_row = [&](auto range, int slot, int ky, int k0, v8h ah, v8h al, auto&& between) {
+        constexpr bool RANGE = decltype(range)::value;
+        if (RANGE && (ky * KS + KS <= tLo || ky * KS >= tHi)) return;      // none of this filter row's taps is this wave's
         const _Float16* src = sX + slot * 2 * XPLANE + (ib * 32 + li) * XP + k0 + 8 * lh;
         const u32x4 h0 = *reinterpret_cast<const u32x4*>(src), h1 = *reinterpret_cast<const u32x4*>(src + 8);
         const u32x4 l0 = *reinterpret_cast<const u32x4*>(src + XPLANE), l1 = *reinterpret_cast<const u32x4*>(src + XPLANE + 8);
         const unsigned wh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
         const unsigned wl[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+        v8h fbh[KS], fbl[KS];
 #pragma unroll
         for (int kx = 0; kx < KS; kx++) {
             u32x4 bh, bl;
@@ -156,35 +174,77 @@ wgrad_f16x3_kernel(WgradParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) { bh[j] = wh[j + kx / 2]; bl[j] = wl[j + kx / 2]; }
             }
-            const v8h fbh = __builtin_bit_cast(v8h, bh), fbl = __builtin_bit_cast(v8h, bl);
-            const int tp = ky * KS + kx;
-            if (tp < tLo || tp >= tHi) continue;                           // wave-uniform
-            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fbh, acc[tp], 0, 0, 0);
-            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fbl, acc[tp], 0, 0, 0);
-            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fbh, acc[tp], 0, 0, 0);
+            fbh[kx] = __builtin_bit_cast(v8h, bh); fbl[kx] = __builtin_bit_cast(v8h, bl);
+        }
+        if (RANGE) {
+#pragma unroll
+            for (int kx = 0; kx < KS; kx++) {
+                const int tp = ky * KS + kx;
+                if (tp < tLo || tp >= tHi) continue;                       // wave-uniform
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fbh[kx], acc[tp], 0, 0, 0);
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fbl[kx], acc[tp], 0, 0, 0);
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fbh[kx], acc[tp], 0, 0, 0);
+            }
+        } else {
+            // part by part over the shifts; `between` (a slice of the next row's hand-over, or nothing) follows each group of KS
+            // MFMAs and is fenced there, so that its vector work runs in the shadow of the matrix pipe instead of after it
+#pragma unroll
+            for (int kx = 0; kx < KS; kx++) acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, fbh[kx], acc[ky * KS + kx], 0, 0, 0);
+            between(ky * 3 + 0);
+#pragma unroll
+            for (int kx = 0; kx < KS; kx++) acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fbl[kx], acc[ky * KS + kx], 0, 0, 0);
+            between(ky * 3 + 1);
+#pragma unroll
+            for (int kx = 0; kx < KS; kx++) acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, fbh[kx], acc[ky * KS + kx], 0, 0, 0);
+            between(ky * 3 + 2);
         }
     };
+    auto mfma_step = [&](auto range, int y, int k0, auto&& between) {
+        const _Float16* asrc = sD + (y & 1) * 2 * DPLANE + (ob * 32 + li) * DP + k0 + 8 * lh;
+        const v8h ah = *reinterpret_cast<const v8h*>(asrc), al = *reinterpret_cast<const v8h*>(asrc + DPLANE);
+#pragma unroll
+        for (int ky = 0; ky < KS; ky++) taps_of_row(range, (y + ky) % RING, ky, k0, ah, al, between);
+    };
+    const bool wholeBlock = blockReal && tLo == 0 && tHi == TAPS;        // wave-uniform: one block, all taps (every wave of a full tile)
 
+    auto run = [&](auto range) {
+    unsigned vd[8], vx[12];
     for (int seg = seg0; seg < seg1; seg++) {
         const int xs = seg * KT;                        // first dy column of the segment = first padded-input column
-        // ring warm-up: padded rows y0 .. y0 + KS - 2
+        __syncthreads();                                // the previous segment's fragment reads are done
+        // ring warm-up: padded rows y0 .. y0 + KS - 1 and the first dy row
+#pragma unroll
+        for (int r = 0; r < KS - 1; r++) { load_x(y0 + r, xs, vx, true); write_x(vx, (y0 + r) % RING); }
+        load_dy(y0, xs, vd, true); load_x(y0 + KS - 1, xs, vx, true);
+        write_dy(vd, y0 & 1); write_x(vx, (y0 + KS - 1) % RING);
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < KS - 1; r++) stage_x(y0 + r, xs, (y0 + r) % RING);
         for (int y = y0; y < y1; y++) {
-            __syncthreads();                            // the previous row's fragment reads are done
-            stage_dy(y, xs);
-            stage_x(y + KS - 1, xs, (y + KS - 1) % RING);
-            __syncthreads();
-#pragma unroll
-            for (int k0 = 0; k0 < KT; k0 += 16) {
-                const _Float16* asrc = sD + (ob * 32 + li) * DP + k0 + 8 * lh;
-                const v8h ah = *reinterpret_cast<const v8h*>(asrc), al = *reinterpret_cast<const v8h*>(asrc + DPLANE);
-#pragma unroll
-                for (int ky = 0; ky < KS; ky++) taps_of_row((y + ky) % RING, ky, k0, ah, al);
+            // One barrier per row: the next row's samples are requested before this row's MFMAs and handed to LDS between its two K
+            // steps (their split runs in the shadow of the matrix pipe), into the other dy buffer and the ring slot that row y - 1
+            // released (both last read before the previous barrier).  Branch-free: past the band's last row the requests are out of
+            // range (zeros, no traffic) and land in buffers nobody reads
+            const bool more = y + 1 < y1;
+            load_dy(y + 1, xs, vd, more); load_x(y + KS, xs, vx, more);
+            mfma_step(range, y, 0, [](int) {});
+            if (decltype(range)::value || KS != 3) {
+                write_dy(vd, (y + 1) & 1); write_x(vx, (y + KS) % RING);
+                mfma_step(range, y, 16, [](int) {});
+            } else {
+                // ten slices of the hand-over (4 dy row pairs, 6 input pairs) behind the nine MFMA groups of the second K step
+                mfma_step(range, y, 16, [&](int g) {
+                    if (g < 4) write_dy_pair(vd, (y + 1) & 1, g);
+                    else write_x_pair(vx, (y + KS) % RING, (g - 4) % 3, 2 * ((g - 4) / 3));
+                    if (g == 8) write_x_pair(vx, (y + KS) % RING, 2, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
             }
+            __syncthreads();
         }
     }
+    };
+    // two copies of the loop nest rather than a test inside it: a merge of the accumulators of two MFMA sites per row would double them
+    if (wholeBlock) run(std::false_type{});
+    else run(std::true_type{});
 
     // partial[split][n][tap][o][i]; C layout: column (i) = lane & 31, row (o) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const float inv = 1.f / (scD * scX);
@@ -213,7 +273,11 @@ static int launch_wgrad(const sg3_wgrad_params& q, hipStream_t st) {
     p.nBands = q.nBands; p.nSegGroups = q.nSegGroups;
     p.bandRows = ceil_div(p.OH, q.nBands); p.segsPerGroup = ceil_div(p.nSegs, q.nSegGroups);
     dim3 g((unsigned)(p.oTiles * p.iTiles * q.N), (unsigned)q.nBands, (unsigned)q.nSegGroups), b(256);
-    hipLaunchKernelGGL((wgrad_f16x3_kernel<T, KS>), g, b, 0, st, p);
+    // LDS image (halfs): two dy buffers + KS + 1 ring slots of the input, hi | lo planes of 64 rows each: 76 KB for 3x3, two workgroups per CU
+    constexpr unsigned ldsBytes = (2u * 2u * 64u * (32 + 8) + (KS + 1) * 2u * 64u * (32 + 16 + 8)) * 2u;
+    auto kern = wgrad_f16x3_kernel<T, KS>;
+    SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+    hipLaunchKernelGGL(kern, g, b, ldsBytes, st, p);
     SG3_LAUNCH_CHECK("wgrad_f16x3_kernel");
     return SG3_OK;
 }
@@ -227,22 +291,37 @@ int sg3_conv2d_wgrad_splits(int N, int I, int O, int H, int W, int k, int pad, i
     SG3_REQUIRE(N > 0 && I > 0 && O > 0 && H > 0 && W > 0 && (k == 1 || k == 3) && nBands && nSegGroups, "conv2d_wgrad_splits: bad arguments");
     const int OH = H + 2 * pad - k + 1, OW = W + 2 * pad - k + 1;
     SG3_REQUIRE(OH > 0 && OW > 0, "conv2d_wgrad_splits: empty output");
-    // enough workgroups to fill 256 CUs a few times over, with bands tall enough that the ring warm-up stays small
+    // 3x3: ONE round of resident workgroups (two per CU on 256 CUs), never more: every further round costs a ring warm-up, a partial
+    // image of 9 x 64 x 64 floats per workgroup and a ragged tail (measured on the T-1024 layers, batch 1: 512 -> 3.17 ms, 1024 ->
+    // 3.37, 2048 -> 3.61, 256 -> 3.64; `SG3_WGRAD_WGS` overrides).  1x1 (ToRGB): short workgroups, a few rounds
+    static const long long forced = [] { const char* e = getenv("SG3_WGRAD_WGS"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : 0; }();
+    const long long target = forced ? forced : (k == 3 ? 512 : 2048);
     const long long tiles = (long long)ceil_div(O, 64) * ceil_div(I, 64) * N;
-    long long want = ceil_div64(2048, tiles);
-    int bands = (int)(want < 1 ? 1 : want);
-    const int maxBands = max(1, OH / 8);
-    int groups = 1;
-    if (bands > maxBands) {
-        groups = (int)ceil_div64(bands, maxBands);
-        bands = maxBands;
-        const int nSegs = ceil_div(OW, 32);
-        if (groups > nSegs) groups = nSegs;
+    long long want = k == 3 ? target / tiles : ceil_div64(target, tiles);
+    if (want < 1) want = 1;
+    const int maxBands = max(1, OH / 8), nSegs = ceil_div(OW, 32);       // bands tall enough that the ring warm-up stays small
+    int bands = 1, groups = 1;
+    if (k == 3) {
+        // the (bands, segment groups) pair with the most workgroups not beyond the target, after dropping empty bands / groups;
+        // ties go to fewer groups (each group restarts the ring for every band)
+        long long best = 0;
+        for (int g = 1; g <= nSegs; g++) {
+            const int gEff = ceil_div(nSegs, ceil_div(nSegs, g));
+            const long long b0 = min((long long)maxBands, want / gEff);
+            if (b0 < 1) break;
+            const int bEff = ceil_div(OH, ceil_div(OH, (int)b0));
+            if ((long long)bEff * gEff > best) { best = (long long)bEff * gEff; bands = bEff; groups = gEff; }
+        }
+    } else {
+        bands = (int)want;
+        if (bands > maxBands) {
+            groups = (int)ceil_div64(bands, maxBands);
+            bands = maxBands;
+            if (groups > nSegs) groups = nSegs;
+        }
+        bands = ceil_div(OH, ceil_div(OH, bands));
+        groups = ceil_div(nSegs, ceil_div(nSegs, groups));
     }
-    // no empty bands / groups
-    bands = ceil_div(OH, ceil_div(OH, bands));
-    const int nSegs = ceil_div(OW, 32);
-    groups = ceil_div(nSegs, ceil_div(nSegs, groups));
     *nBands = bands; *nSegGroups = groups;
     return SG3_OK;
 }
@@ -257,6 +336,9 @@ int sg3_conv2d_wgrad(const sg3_wgrad_params* p, void* stream) {
     SG3_REQUIRE(p->nBands > 0 && p->nSegGroups > 0, "conv2d_wgrad: bad split counts");
     SG3_REQUIRE((int64_t)p->I * p->H * p->W * 4 < (int64_t)1 << 31 && (int64_t)p->O * (p->H + 2) * (p->W + 2) * 4 < (int64_t)1 << 31,
                 "conv2d_wgrad: a sample must stay below 2 GiB (32-bit offsets)");
+    // rows of channel padding (up to the next multiple of 64) are requested beyond num_records: their offsets must not wrap
+    SG3_REQUIRE((int64_t)((p->I + 63) / 64 * 64) * p->H * p->W * 4 < (int64_t)1 << 31 && (int64_t)((p->O + 63) / 64 * 64) * (p->H + 2) * (p->W + 2) * 4 < (int64_t)1 << 31,
+                "conv2d_wgrad: a sample padded to 64 channels must stay below 2 GiB (32-bit offsets)");
     hipStream_t st = (hipStream_t)stream;
     if (p->dtype == SG3_F32) return p->k == 3 ? launch_wgrad<float, 3>(*p, st) : launch_wgrad<float, 1>(*p, st);
     return p->k == 3 ? launch_wgrad<_Float16, 3>(*p, st) : launch_wgrad<_Float16, 1>(*p, st);
