@@ -160,11 +160,7 @@ modconv_f23_kernel(F23Params p) {
         g0 = rowOk && (unsigned)gx < (unsigned)p.W ? (unsigned)(gy * p.W + gx) * 4u : 0x80000000u;
         // every sample is requested ONCE: a thread loads its own column pair; the pair to its right arrives from the next lane
         // through DPP, and only the last pair of a tile row (lane 15 of its 16) requests the two halo columns itself
-#ifdef SG3_F23_NO_DPP
-        g1 = rowOk && (unsigned)(gx + 2) < (unsigned)p.W ? (unsigned)(gy * p.W + gx + 2) * 4u : 0x80000000u;
-#else
         g1 = rowOk && spair == 15 && (unsigned)(gx + 2) < (unsigned)p.W ? (unsigned)(gy * p.W + gx + 2) * 4u : 0x80000000u;
-#endif
     }
     const unsigned gS = (unsigned)(lane & 15) * 4u;                   // style scales: lane c requests channel c of the chunk
     const int sL = srow * 256 + spair * 16 + sch * PLANE;             // + (xi * 2 + part) * 2 * PLANE
@@ -198,11 +194,7 @@ modconv_f23_kernel(F23Params p) {
     f32x2 rb[8][2];
     float rsc;
     constexpr int NB = 17, NA = 6;                                    // loads per input request / per fragment request
-#ifdef SG3_F23_WAIT0
-#define F23_CNT(N) "0"
-#else
 #define F23_CNT(N) #N
-#endif
     // Each request is ONE asm statement that opens with "s_nop 4": hipcc may reload a spilled SGPR with v_readlane right in front
     // of the statement, and an SGPR written by a VALU instruction needs 5 wait states before a vector-memory instruction reads it
     // (descriptor or scalar offset) -- the compiler pads that hazard for its own instructions, not for ones inside an asm string.
@@ -236,18 +228,6 @@ modconv_f23_kernel(F23Params p) {
         // the chunk's channel offset rides in the VECTOR offset of the scale request: only that is range checked, and channels beyond I
         // must read a zero scale (they alias channel 0 of the input)
         const unsigned v0 = in ? g0 : 0x80000000u, v1 = in ? g1 : 0x80000000u, vs = in ? gS + (unsigned)ch * 64u : 0x80000000u;
-#if defined(SG3_F23_BUILTIN) || defined(SG3_F23_BUILTIN_B)
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * p.I * p.H * p.W), (short)0, (int)((unsigned)p.I * HWb), 0x00020000);
-        const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.sIn + (size_t)n * p.I), (short)0, p.I * 4, 0x00020000);
-        rsc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, (int)vs, 0, 0));
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const int ci = ch * 16 + sch * 8 + c;
-            const unsigned coff = ci < p.I ? (unsigned)ci * HWb : 0u;
-            rb[c][0] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)v0, (int)coff, 0));
-            rb[c][1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)v1, (int)coff, 0));
-        }
-#else
         unsigned cf[8];
 #pragma unroll
         for (int c = 0; c < 8; c++) {
@@ -277,16 +257,11 @@ modconv_f23_kernel(F23Params p) {
                      "buffer_load_dwordx2 %7, %9, %10, %14 offen"
                      : "=&v"(rb[4][0]), "=&v"(rb[4][1]), "=&v"(rb[5][0]), "=&v"(rb[5][1]), "=&v"(rb[6][0]), "=&v"(rb[6][1]), "=&v"(rb[7][0]), "=&v"(rb[7][1])
                      : "v"(v0), "v"(v1), "s"(xd), "s"(cf[4]), "s"(cf[5]), "s"(cf[6]), "s"(cf[7]) : "memory");
-#endif
     };
     // AUDIT after every edit (tools/audit_f23_asm.py on the -save-temps .s): between a hand-issued load and the wait that covers it
     // hipcc must not read or copy the destination registers (it treats them as written when the load is issued).
-#if defined(SG3_F23_BUILTIN) || defined(SG3_F23_BUILTIN_B)
-#define F23_WAIT_B(N) do { } while (0)
-#else
 #define F23_WAIT_B(N) asm volatile("s_waitcnt vmcnt(" F23_CNT(N) ")" : "+v"(rsc), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]), \
         "+v"(rb[3][0]), "+v"(rb[3][1]), "+v"(rb[4][0]), "+v"(rb[4][1]), "+v"(rb[5][0]), "+v"(rb[5][1]), "+v"(rb[6][0]), "+v"(rb[6][1]), "+v"(rb[7][0]), "+v"(rb[7][1]) :: "memory")
-#endif
     static_assert(NB == 17 && NA == 6, "the wait counts below are written for these request sizes");
 
     auto stage = [&](int buf) {
@@ -296,28 +271,17 @@ modconv_f23_kernel(F23Params p) {
         f32x2 v03[8], v12[8];
 #pragma unroll
         for (int c = 0; c < 8; c++) {
-#ifdef SG3_F23_CSTAGE
-            const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rsc), sch * 8 + c));
-            float nx = rb[c][1].x, ny = rb[c][1].y;
-            asm("v_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(nx) : "v"(rb[c][0].x));
-            asm("v_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(ny) : "v"(rb[c][0].y));
-            const float d0 = rb[c][0].x * sc, d1 = rb[c][0].y * sc, d2 = nx * sc, d3 = ny * sc;
-            v03[c] = (f32x2){d0 - d2, d1 - d3}; v12[c] = (f32x2){d1 + d2, d2 - d1};
-#else
             const unsigned long long sc2 = (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, rsc), sch * 8 + c);   // low half: the scale
             // columns (2p+2, 2p+3) = the own pair of the lane to the right (row_shl: lane i takes lane i + 1 of its row of 16; the
             // last lane of a row has no source and keeps what it loaded: the halo pair)
             float nx = rb[c][1].x, ny = rb[c][1].y;
-#ifndef SG3_F23_NO_DPP
             asm("v_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(nx) : "v"(rb[c][0].x));
             asm("v_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(ny) : "v"(rb[c][0].y));
-#endif
             const f32x2 right = {nx, ny};
             f32x2 t;
             asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(right), "s"(sc2));
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(v03[c]) : "v"(rb[c][0]), "s"(sc2), "v"(t));
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] neg_hi:[1,0,0]" : "=v"(v12[c]) : "v"(rb[c][0]), "s"(sc2), "v"(t));
-#endif
         }
         unsigned char* dst = sm + buf * BUF + sL;
 #pragma unroll
@@ -327,16 +291,10 @@ modconv_f23_kernel(F23Params p) {
             for (int c = 0; c < 4; c++) {
                 const float x0 = t == 0 ? v03[2 * c].x : (t == 1 ? v12[2 * c].x : (t == 2 ? v12[2 * c].y : v03[2 * c].y));
                 const float x1 = t == 0 ? v03[2 * c + 1].x : (t == 1 ? v12[2 * c + 1].x : (t == 2 ? v12[2 * c + 1].y : v03[2 * c + 1].y));
-#ifdef SG3_F23_CSPLIT
-                v2h h2, l2;
-                split2(x0, x1, h2, l2);
-                const unsigned h = __builtin_bit_cast(unsigned, h2), l = __builtin_bit_cast(unsigned, l2);
-#else
                 const unsigned h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
                 unsigned l;
                 asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=&v"(l) : "v"(h), "v"(x0));
                 asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x1));
-#endif
                 hv[c] = h; lv[c] = l;
             }
             if (sOk) {
@@ -353,11 +311,6 @@ modconv_f23_kernel(F23Params p) {
     };
     // an M block of pure channel padding (O = 203: channels 224..255 of the fourth tile) stages and synchronises but issues no MFMAs
     const bool active = o0 + mb * 32 < p.O;                                  // wave-uniform
-#ifdef SG3_F23_E3
-#define F23_E3 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" ::: "memory");
-#else
-#define F23_E3
-#endif
     auto mfma_chunk = [&](int buf) {
         if (!active) return;
 #if F23_PRIO_MODE == 1
@@ -372,22 +325,17 @@ modconv_f23_kernel(F23Params p) {
         if constexpr ((Q) < TN + 2) { \
             if constexpr ((Q) + 1 < TN + 2) load_b(b1, buf, (Q) + 1); \
             __builtin_amdgcn_sched_barrier(0); \
-            F23_E3 \
             f23_mfma_row<TN, (Q)>(b0.h, b0.l); \
             __builtin_amdgcn_sched_barrier(0); \
             if constexpr ((Q) + 1 < TN + 2) { \
                 if constexpr ((Q) + 2 < TN + 2) load_b(b0, buf, (Q) + 2); \
                 __builtin_amdgcn_sched_barrier(0); \
-                F23_E3 \
-                f23_mfma_row<TN, (Q) + 1>(b1.h, b1.l); \
+                    f23_mfma_row<TN, (Q) + 1>(b1.h, b1.l); \
                 __builtin_amdgcn_sched_barrier(0); \
             } \
         }
         F23_ROWPAIR(0) F23_ROWPAIR(2) F23_ROWPAIR(4) F23_ROWPAIR(6) F23_ROWPAIR(8)
 #undef F23_ROWPAIR
-#ifdef SG3_F23_E1
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#endif
         static_assert(TN + 2 <= 10, "row pairs spelled out for up to ten patch rows");
 #if F23_PRIO_MODE == 1
         __builtin_amdgcn_s_setprio(0);
