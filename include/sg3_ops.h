@@ -500,6 +500,25 @@ typedef struct sg3_se_params {
 
 SG3_API int sg3_se_residual(const sg3_se_params* p, void* stream);
 
+/* ----------------------------------------------------------------------
+ * unfold3x3s2 -- the patch matrix of a 3x3, stride-2, padding-1 convolution, for the batched GEMMs of the GradualStyleBlock heads
+ *   (models/setgan/encoder/encoders/map2style.py:8-25: Conv2d(3x3, stride 2, padding 1) + LeakyReLU per level;
+ *   restyle_psp_encoders.py:26-50).  One launch per level instead of the pad / slice / stack / permute chain:
+ *       dst[g][(n*OH + oy)*OW + ox][tap*C + c] = act(src[g,n,c, 2*oy + ky - 1, 2*ox + kx - 1]),  0 outside the map,
+ *   tap = ky*3 + kx, OH = (IH+1)/2, OW = (IW+1)/2, act = LeakyReLU(slope) of the previous level (slope 1 = none).
+ *   src is addressed through element strides, so it may be the channels-first strip a convolution wrote or the
+ *   [g][n*pixels][c] rows of the previous level's GEMM.  float32.
+ * ---------------------------------------------------------------------- */
+typedef struct sg3_unfold_params {
+    const float*   src;
+    int64_t        srcStride[5];   /* elements: g, n, c, y, x */
+    float*         dst;            /* [G][N*OH*OW][9*C] dense */
+    int32_t        G, N, C, IH, IW;
+    float          slope;
+} sg3_unfold_params;
+
+SG3_API int sg3_unfold3x3s2(const sg3_unfold_params* p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

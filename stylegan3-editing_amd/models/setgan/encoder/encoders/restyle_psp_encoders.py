@@ -3,7 +3,8 @@
 `BackboneEncoder` (:10-50): conv3x3(input_nc -> 64) + BN + PReLU at 256^2, the IR / IR-SE stages down to [N,512,16,16],
 then `n_styles` GradualStyleBlock heads, stacked to [N, n_styles, 512].  Module names and therefore state_dict keys are
 the reference's.  In eval mode on a GPU the backbone runs on libsg3hip's matrix-core convolution with BatchNorm / PReLU
-fused, and the style heads (tiny maps, weight-bandwidth bound) as batched GEMMs over all heads on unfolded patches.
+fused; the first level of all style heads as one strip convolution on the same kernel, the deeper levels (tiny maps,
+weight-bandwidth bound) as batched GEMMs over all heads on patches written by `sg3_unfold3x3s2`.
 `ResNetBackboneEncoder` (:53-97): the same heads on a ResNet34 trunk (7x7 stride-2 stem without max-pool, then torchvision's
 layer1..layer4 BasicBlocks flattened into `body`, so the keys are `conv1 / bn1 / relu / body.{0..15}.{conv1,bn1,conv2,bn2,
 downsample.{0,1}} / styles.*`).  The reference seeds the trunk from `torchvision.models.resnet34(pretrained=True)`, which is
@@ -16,17 +17,6 @@ from torch.nn import BatchNorm2d, Conv2d, Module, PReLU, Sequential
 
 from models.setgan.encoder.encoders.helpers import bottleneck_IR, bottleneck_IR_SE, get_blocks, resnet34_blocks
 from models.setgan.encoder.encoders.map2style import GradualStyleBlock
-
-
-def _patches_3x3_s2(h):
-    """im2col of a 3x3, stride-2, padding-1 convolution: [B,C,H,W] -> [B, C*9, (H/2)*(W/2)] in F.unfold's ordering
-    (channel-major, then ky, kx).  Nine strided slices and one stack: F.unfold launches one kernel per batch element, and
-    the heads run with B = heads * N."""
-    b, c, hh, ww = h.shape
-    oh, ow = (hh + 1) // 2, (ww + 1) // 2
-    hp = torch.nn.functional.pad(h, (1, 1, 1, 1))
-    taps = [hp[:, :, ky:ky + 2 * oh - 1:2, kx:kx + 2 * ow - 1:2] for ky in range(3) for kx in range(3)]
-    return torch.stack(taps, dim=2).reshape(b, c * 9, oh * ow)
 
 
 class _StyleHeadEncoder(Module):
@@ -79,20 +69,24 @@ class _StyleHeadEncoder(Module):
     def _pack(self):
         pk = {}
         self._pack_trunk(pk)
-        # Head convolutions.  Every style block starts from the same [N,512,16,16] map and halves it to 8x8, 4x4, 2x2,
-        # 1x1: far too few pixels for an implicit-GEMM tile, and what bounds them is reading the weights (16 heads x 4
-        # levels x 9.4 MB).  They run as plain GEMMs on patches taken with unfold: the first level of all heads as ONE
-        # [N*64, 512*9] x [512*9, heads*512] product,
-        pk['head0_w'] = torch.cat([s.convs[0].weight.reshape(s.out_c, -1) for s in self.styles], dim=0).t().contiguous()   # [I*9, heads*O]
-        pk['head0_b'] = torch.cat([s.convs[0].bias for s in self.styles], dim=0).unsqueeze(0)
-        # the remaining levels as ONE batched GEMM per level over all heads: [heads, N*pixels, 512*9] x [heads, 512*9, 512]
+        # Head convolutions.  Every style block starts from the same [N,512,16,16] map and halves it to 8x8, 4x4, 2x2, 1x1.
+        # Level 1 of ALL heads is one stride-2 convolution with heads * 512 output channels on the split-precision matrix-core kernel
+        # (bias + LeakyReLU in its epilogue): 77 GFLOP at batch 16, compute bound.  Its 8x8 output maps are too few pixels for the
+        # kernel's 4-row x 32-column tile, so the N images travel side by side as ONE strip image (see _forward_kernels).
+        from torch_utils.ops.plain_conv import ACT_LRELU, PackedConv
+        dev = self.styles[0].convs[0].weight.device
+        pk['slope'] = float(self.styles[0].convs[1].negative_slope)
+        pk['head0'] = PackedConv(torch.cat([s.convs[0].weight for s in self.styles], dim=0), bias=torch.cat([s.convs[0].bias for s in self.styles], dim=0),
+                                 act=ACT_LRELU, slope=torch.full([1], pk['slope'], device=dev), stride=2, padding=1)
+        # From level 2 on every head has its own input: tiny maps, bounded by reading the weights (heads x 9.4 MB per level): ONE
+        # batched GEMM per level over all heads, [heads, N*pixels, 9*512] x [heads, 9*512, 512], on patches written by one launch of
+        # sg3_unfold3x3s2 (rows ordered tap-major, channels innermost: the weights' rows are permuted to match)
         n_levels = (len(self.styles[0].convs) // 2) - 1
-        pk['tail_w'] = [torch.stack([s.convs[2 * (l + 1)].weight.reshape(s.out_c, -1).t() for s in self.styles]).contiguous()
-                        for l in range(n_levels)]                                                       # [heads, I*9, O]
+        pk['tail_w'] = [torch.stack([s.convs[2 * (l + 1)].weight.permute(2, 3, 1, 0).reshape(-1, s.out_c) for s in self.styles]).contiguous()
+                        for l in range(n_levels)]                                                       # [heads, 9*I, O]
         pk['tail_b'] = [torch.stack([s.convs[2 * (l + 1)].bias for s in self.styles]).unsqueeze(1) for l in range(n_levels)]
         pk['lin_w'] = torch.stack([(s.linear.weight * s.linear.scale).t() for s in self.styles]).contiguous()   # [heads, in, out]
         pk['lin_b'] = torch.stack([s.linear.bias * s.linear.lr_mul for s in self.styles]).unsqueeze(1)
-        pk['slope'] = float(self.styles[0].convs[1].negative_slope)
         self._packed = pk
 
     def _forward_hip(self, x):
@@ -117,20 +111,33 @@ class _StyleHeadEncoder(Module):
             self._pack()
             self._packed_key = key
         pk = self._packed
+        from torch_utils.ops.unfold_ops import unfold3x3s2
         x = self._trunk_hip(pk, x.float())
-        n, heads, c = int(x.shape[0]), len(self.styles), self.styles[0].out_c
-        side = (int(x.shape[2]) + 1) // 2
-        cols = _patches_3x3_s2(x)                                                                     # [N, C*9, side^2]
-        cols = cols.permute(0, 2, 1).reshape(n * side * side, -1)
-        h = torch.nn.functional.leaky_relu(torch.addmm(pk['head0_b'], cols, pk['head0_w']), pk['slope'])   # [N*side^2, heads*C]
-        h = h.view(n, side, side, heads, c).permute(3, 0, 4, 1, 2).reshape(heads * n, c, side, side)
+        n, ci, sh, sw = (int(v) for v in x.shape)
+        heads, c = len(self.styles), self.styles[0].out_c
+        # The strip: image i occupies columns [period*i, period*i + sw) of a [1, C, sh, period*N] image whose other columns stay zero;
+        # period is even and > sw, so every image starts on an even column (stride 2 keeps each image's own pixel parity) and finds
+        # its zero padding in the gap.  Output column (period/2)*i + ox is pixel ox of image i (one junk column per image for even sw).
+        period = sw + 2 - (sw & 1)
+        if pk.get('strip_key') != (n, ci, sh, sw, x.device):
+            pk['strip'] = torch.zeros([1, ci, sh, period * n], dtype=torch.float32, device=x.device)
+            pk['strip_key'] = (n, ci, sh, sw, x.device)
+        pk['strip'][0].view(ci, sh, n, period)[..., :sw].copy_(x.permute(1, 2, 0, 3))
+        h = pk['head0'].run(pk['strip'])                                                              # [1, heads*C, oh, (period/2)*N]
+        oh, ow = (sh + 1) // 2, (sw + 1) // 2
+        src = h[0].view(heads, c, oh, n, period // 2)[..., :ow].permute(0, 3, 1, 2, 4)                # [heads, N, C, oh, ow] view
+        slope = 1.0                                                                                   # level 1 leaves the kernel activated
+        hh = None
         for w, b in zip(pk['tail_w'], pk['tail_b']):
-            side = (int(h.shape[2]) + 1) // 2
-            cols = _patches_3x3_s2(h)                                                              # [heads*N, C*9, side^2]
-            cols = cols.view(heads, n, c * 9, side * side).permute(0, 1, 3, 2).reshape(heads, n * side * side, c * 9)
-            h = torch.nn.functional.leaky_relu(torch.baddbmm(b, cols, w), pk['slope'])           # [heads, N*side^2, C]
-            h = h.view(heads, n, side, side, c).permute(0, 1, 4, 2, 3).reshape(heads * n, c, side, side)
-        codes = torch.baddbmm(pk['lin_b'], h.view(heads, n, c), pk['lin_w'])                       # EqualLinear of every head
+            cols = unfold3x3s2(src, slope)                                                         # [heads, N*oh'*ow', 9*C]
+            oh, ow = (oh + 1) // 2, (ow + 1) // 2
+            hh = torch.baddbmm(b, cols, w)                                                         # [heads, N*oh*ow, C], before its LeakyReLU
+            src = hh.view(heads, n, oh, ow, c).permute(0, 1, 4, 2, 3)
+            slope = pk['slope']
+        if oh * ow != 1 or hh is None:
+            raise RuntimeError(f'style heads: a {sh}x{sw} feature map does not reduce to 1x1 in {len(pk["tail_w"]) + 1} halvings')
+        last = torch.nn.functional.leaky_relu(hh.view(heads, n, c), pk['slope'])
+        codes = torch.baddbmm(pk['lin_b'], last, pk['lin_w'])                                     # EqualLinear of every head
         return self._combine(list(codes.unbind(0)))
 
     def forward(self, x):

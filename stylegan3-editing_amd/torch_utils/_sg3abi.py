@@ -76,6 +76,11 @@ class SeParams(ctypes.Structure):
                 ('N', c_i32), ('C', c_i32), ('H', c_i32), ('W', c_i32), ('R', c_i32)]
 
 
+class UnfoldParams(ctypes.Structure):
+    _fields_ = [('src', c_vp), ('srcStride', c_i64 * 5), ('dst', c_vp), ('G', c_i32), ('N', c_i32), ('C', c_i32), ('IH', c_i32), ('IW', c_i32),
+                ('slope', c_f32)]
+
+
 class AffineBatchParams(ctypes.Structure):
     _fields_ = [('ws', c_vp), ('wsStrideN', c_i64), ('wsStrideL', c_i64), ('weight', c_vp), ('bias', c_vp), ('scale', c_vp),
                 ('rowStart', c_vp), ('wsIndex', c_vp), ('out', c_vp), ('N', c_i32), ('wDim', c_i32), ('layers', c_i32), ('rows', c_i32)]
@@ -121,6 +126,7 @@ EXPORTS = [
     ('sg3_input_transform', ctypes.c_int, [ctypes.POINTER(InputTransformParams), c_vp]),
     ('sg3_affine_batch', ctypes.c_int, [ctypes.POINTER(AffineBatchParams), c_vp]),
     ('sg3_se_residual', ctypes.c_int, [ctypes.POINTER(SeParams), c_vp]),
+    ('sg3_unfold3x3s2', ctypes.c_int, [ctypes.POINTER(UnfoldParams), c_vp]),
     ('sg3_modulation_backward', ctypes.c_int, [ctypes.POINTER(ModgradParams), c_vp]),
     ('sg3_modulated_conv2d_prep', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), c_vp]),
     ('sg3_modulated_conv2d_prep_batch', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), ctypes.c_int, c_vp]),

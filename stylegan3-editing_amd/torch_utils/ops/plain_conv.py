@@ -66,6 +66,9 @@ class PackedConv:
         return self._packed[prec]
 
     def __call__(self, x):
+        return self.run(x)
+
+    def run(self, x):
         assert x.is_cuda and x.dtype == torch.float32 and x.ndim == 4 and x.shape[1] == self.I
         x = x.contiguous()
         n, _, h, w = (int(v) for v in x.shape)

@@ -39,7 +39,7 @@ def test_struct_layout_matches_header():
                        ('sg3_upfirdn2d_params', _sg3abi.Upfirdn2dParams), ('sg3_bias_act_params', _sg3abi.BiasActParams),
                        ('sg3_modconv_params', _sg3abi.ModconvParams), ('sg3_modconv_prep_params', _sg3abi.ModconvPrepParams),
                        ('sg3_conv2d_params', _sg3abi.Conv2dParams), ('sg3_wgrad_params', _sg3abi.WgradParams),
-                       ('sg3_fourier_params', _sg3abi.FourierParams)):
+                       ('sg3_fourier_params', _sg3abi.FourierParams), ('sg3_se_params', _sg3abi.SeParams), ('sg3_unfold_params', _sg3abi.UnfoldParams)):
         body = re.search(r'typedef struct ' + cname + r' \{(.*?)\} ' + cname + ';', src, re.S).group(1)
         body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
         names = []

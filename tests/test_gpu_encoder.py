@@ -184,3 +184,30 @@ def test_se_residual_kernels(n, c, h, w, strided):
     out = se_ops.se_residual(buf, shortcut, fc1, fc2)
     assert out.data_ptr() == buf.data_ptr()
     assert float((out - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('g,n,c,ih,iw,layout,slope', [
+    (3, 2, 70, 8, 8, 'strip', 1.0), (16, 16, 512, 8, 8, 'strip', 1.0), (2, 3, 130, 5, 7, 'strip', 0.2),
+    (4, 5, 96, 4, 4, 'rows', 0.01), (16, 16, 512, 2, 2, 'rows', 0.01), (2, 3, 33, 1, 1, 'rows', 0.3), (1, 2, 512, 3, 5, 'rows', 1.0)])
+def test_unfold3x3s2_matches_torch_unfold(g, n, c, ih, iw, layout, slope):
+    """sg3_unfold3x3s2 (the patch matrix of the style heads' stride-2 convolutions, map2style.py:8-25) against F.unfold of the
+    activated input, for both source layouts the encoder hands it: the channels-first strip the level-1 convolution writes (images
+    side by side with junk columns between them) and the pixel-major rows of a batched GEMM.  Bit-exact (pure data movement + one
+    multiply)."""
+    from torch_utils.ops.unfold_ops import unfold3x3s2
+    r = np.random.RandomState(g * 100 + c)
+    if layout == 'strip':
+        period = iw + 3
+        base = torch.from_numpy(r.randn(1, g * c, ih, period * n).astype(np.float32)).to(DEV)
+        src = base[0].view(g, c, ih, n, period)[..., :iw].permute(0, 3, 1, 2, 4)
+    else:
+        base = torch.from_numpy(r.randn(g, n * ih * iw, c).astype(np.float32)).to(DEV)
+        src = base.view(g, n, ih, iw, c).permute(0, 1, 4, 2, 3)
+    assert tuple(src.shape) == (g, n, c, ih, iw)
+    got = unfold3x3s2(src, slope)
+    dense = torch.nn.functional.leaky_relu(src.contiguous(), slope).reshape(g * n, c, ih, iw)
+    oh, ow = (ih + 1) // 2, (iw + 1) // 2
+    ref = torch.nn.functional.unfold(dense, 3, padding=1, stride=2)                      # [g*n, c*9, oh*ow], rows c*9 + tap
+    ref = ref.view(g, n, c, 9, oh * ow).permute(0, 1, 4, 3, 2).reshape(g, n * oh * ow, 9 * c)   # -> rows (n, pixel), columns tap*c + ch
+    assert tuple(got.shape) == tuple(ref.shape)
+    assert torch.equal(got, ref)
