@@ -448,7 +448,7 @@ typedef struct sg3_conv2d_params {
     int32_t        N, I, O, H, W;
     int32_t        k, stride, pad;
     int32_t        act;
-    int32_t        precision;  /* SG3_CONV_FP32 (exact) | SG3_CONV_F16X3 (3x3, stride 1 or 2: fp16 x 3 split, fp32-equivalent) */
+    int32_t        precision;  /* SG3_CONV_FP32 (exact) | SG3_CONV_F16X3 (1x1 / 3x3, stride 1 or 2: fp16 x 3 split, fp32-equivalent) */
     int32_t*       rangeFlag;  /* f16x3: device int, OR-ed with 1 when an operand left the fp16 range (the result of that
                                 * call is then invalid and the caller repeats it with SG3_CONV_FP32); never cleared here */
 } sg3_conv2d_params;

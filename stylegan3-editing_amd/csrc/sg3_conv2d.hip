@@ -187,10 +187,10 @@ conv2d_pack_kernel(const float* w, const float* outScale, float* wp, int O, int 
 // staging and raises `*flag` when it exceeds the fp16 range -- the caller then repeats the layer stack on the exact
 // fp32 kernel (torch_utils/ops/plain_conv.py).  Weights are packed [O][I/16][tap][hi|lo][16] halfs by
 // conv2d_pack_f16x3_kernel with the folded BatchNorm scale applied before the split.
-template <int STRIDE, int WM, int WN, int TM, int TN>
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(256, (TM * TN <= 4) ? 2 : 1)
 conv2d_f16x3_kernel(PlainConvParams p, int* flag) {
-    constexpr int KS = 3, TAPS = 9, KC = 16;
+    constexpr int TAPS = KS * KS, KC = 16;
     constexpr int BM = WM * TM * 32;
     constexpr int ROWS = WN * TN;
     constexpr int PH = (ROWS - 1) * STRIDE + KS, PW = 31 * STRIDE + KS;
@@ -433,35 +433,35 @@ conv2d_f16x3_kernel(PlainConvParams p, int* flag) {
 }
 
 __global__ void __launch_bounds__(256)
-conv2d_pack_f16x3_kernel(const float* w, const float* outScale, float* wp, int O, int I, int nch) {
+conv2d_pack_f16x3_kernel(const float* w, const float* outScale, float* wp, int O, int I, int nch, int taps) {
     const int o = blockIdx.x;
     const float sc = outScale ? outScale[o] : 1.f;
-    _Float16* dst = reinterpret_cast<_Float16*>(wp) + (size_t)o * nch * 9 * 32;
-    for (int j = threadIdx.x; j < nch * 9 * 16; j += 256) {
-        const int c = j % 16, t = (j / 16) % 9, ch = j / (16 * 9);
+    _Float16* dst = reinterpret_cast<_Float16*>(wp) + (size_t)o * nch * taps * 32;
+    for (int j = threadIdx.x; j < nch * taps * 16; j += 256) {
+        const int c = j % 16, t = (j / 16) % taps, ch = j / (16 * taps);
         const int i = ch * 16 + c;
-        const float v = i < I ? w[((size_t)o * I + i) * 9 + t] * sc : 0.f;
+        const float v = i < I ? w[((size_t)o * I + i) * taps + t] * sc : 0.f;
         const _Float16 h = (_Float16)v;
-        _Float16* d = dst + ((size_t)ch * 9 + t) * 32 + c;
+        _Float16* d = dst + ((size_t)ch * taps + t) * 32 + c;
         d[0] = h;
         d[16] = (_Float16)(v - (float)h);
     }
 }
 
-template <int STRIDE, int WM, int WN, int TM, int TN>
+template <int KS, int STRIDE, int WM, int WN, int TM, int TN>
 static int launch_plain_f16x3(const sg3_conv2d_params& q, hipStream_t st) {
     constexpr int BM = WM * TM * 32, ROWS = WN * TN;
-    constexpr size_t ldsBytes = ((size_t)BM * (9 * 32 + 8) + 4 * (size_t)((ROWS - 1) * STRIDE + 3) * (31 * STRIDE + 3) * 8) * sizeof(_Float16);
+    constexpr size_t ldsBytes = ((size_t)BM * (KS * KS * 32 + 8) + 4 * (size_t)((ROWS - 1) * STRIDE + KS) * (31 * STRIDE + KS) * 8) * sizeof(_Float16);
     PlainConvParams p;
     p.x = q.x; p.wp = q.wPacked; p.inScale = q.inScale; p.inShift = q.inShift; p.bias = q.bias; p.slope = q.slope; p.out = q.out;
     p.N = q.N; p.I = q.I; p.O = q.O; p.H = q.H; p.W = q.W; p.stride = STRIDE; p.pad = q.pad; p.act = q.act;
-    p.outH = (q.H + 2 * q.pad - 3) / STRIDE + 1; p.outW = (q.W + 2 * q.pad - 3) / STRIDE + 1;
+    p.outH = (q.H + 2 * q.pad - KS) / STRIDE + 1; p.outW = (q.W + 2 * q.pad - KS) / STRIDE + 1;
     p.nch = ceil_div(q.I, 16);
     p.xTiles = ceil_div(p.outW, 32); p.yTiles = ceil_div(p.outH, ROWS); p.mTiles = ceil_div(q.O, BM);
     const long long total = (long long)p.xTiles * p.yTiles * p.mTiles * q.N;
     if (total > 0x7fffffffLL) { set_error("conv2d: grid too large"); return SG3_BAD_ARG; }
     p.totalBlocks = (int)total;
-    auto kern = conv2d_f16x3_kernel<STRIDE, WM, WN, TM, TN>;
+    auto kern = conv2d_f16x3_kernel<KS, STRIDE, WM, WN, TM, TN>;
     if (ldsBytes > 64 * 1024)
         SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), ldsBytes, st, p, q.rangeFlag);
@@ -470,10 +470,12 @@ static int launch_plain_f16x3(const sg3_conv2d_params& q, hipStream_t st) {
 }
 
 static int dispatch_plain_f16x3(const sg3_conv2d_params& q, hipStream_t st) {
-    if (q.stride == 2) return launch_plain_f16x3<2, 1, 4, 2, 1>(q, st);           // 64 x (4 rows x 32), 9 x 65 patch
+    if (q.k == 1)                                                                    // the projection shortcuts: same kernel, one tap
+        return q.stride == 2 ? launch_plain_f16x3<1, 2, 1, 4, 2, 1>(q, st) : launch_plain_f16x3<1, 1, 1, 4, 2, 1>(q, st);
+    if (q.stride == 2) return launch_plain_f16x3<3, 2, 1, 4, 2, 1>(q, st);        // 64 x (4 rows x 32), 9 x 65 patch
     const int outH = q.H + 2 * q.pad - 2;
-    if (outH <= 16) return launch_plain_f16x3<1, 1, 4, 2, 1>(q, st);              // 64 x (4 rows x 32): the 16x16 maps
-    return launch_plain_f16x3<1, 1, 4, 2, 2>(q, st);                              // 64 x (8 rows x 32)
+    if (outH <= 16) return launch_plain_f16x3<3, 1, 1, 4, 2, 1>(q, st);           // 64 x (4 rows x 32): the 16x16 maps
+    return launch_plain_f16x3<3, 1, 1, 4, 2, 2>(q, st);                           // 64 x (8 rows x 32)
 }
 
 template <int KS, int STRIDE, int WM, int WN, int TM, int TN>
@@ -509,9 +511,9 @@ extern "C" {
 int sg3_conv2d_pack(const float* w, const float* outScale, float* wPacked, int O, int I, int k, int precision, void* stream) {
     using namespace sg3;
     SG3_REQUIRE(w && wPacked && O > 0 && I > 0 && (k == 1 || k == 3), "conv2d_pack: bad arguments");
-    SG3_REQUIRE(precision == SG3_CONV_FP32 || (precision == SG3_CONV_F16X3 && k == 3), "conv2d_pack: f16x3 packing is for 3x3 kernels");
+    SG3_REQUIRE(precision == SG3_CONV_FP32 || precision == SG3_CONV_F16X3, "conv2d_pack: bad precision");
     if (precision == SG3_CONV_F16X3) {
-        hipLaunchKernelGGL(conv2d_pack_f16x3_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, w, outScale, wPacked, O, I, ceil_div(I, 16));
+        hipLaunchKernelGGL(conv2d_pack_f16x3_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, w, outScale, wPacked, O, I, ceil_div(I, 16), k * k);
         SG3_LAUNCH_CHECK("conv2d_pack_f16x3_kernel");
         return SG3_OK;
     }
@@ -533,7 +535,7 @@ int sg3_conv2d(const sg3_conv2d_params* p, void* stream) {
     SG3_REQUIRE(p->H + 2 * p->pad >= p->k && p->W + 2 * p->pad >= p->k, "conv2d: empty output");
     hipStream_t st = (hipStream_t)stream;
     if (p->precision == SG3_CONV_F16X3) {
-        SG3_REQUIRE(p->k == 3 && p->rangeFlag, "conv2d: the f16x3 form takes 3x3 kernels and a range flag");
+        SG3_REQUIRE(p->rangeFlag, "conv2d: the f16x3 form takes a range flag");
         SG3_REQUIRE((int64_t)p->I * p->H * p->W * 4 < (int64_t)1 << 31, "conv2d: f16x3 needs a sample below 2 GiB (32-bit offsets)");
         return dispatch_plain_f16x3(*p, st);
     }

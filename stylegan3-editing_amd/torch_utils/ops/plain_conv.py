@@ -14,7 +14,8 @@ from .. import _sg3abi as abi
 
 ACT_NONE, ACT_PRELU, ACT_LRELU = 0, 1, 2
 
-# Arithmetic of the 3x3 convolutions (stride 1: the bulk of the backbone; stride 2: the first unit of each stage):
+# Arithmetic of the convolutions (3x3 stride 1: the bulk of the backbone; 3x3 stride 2: the first unit of each stage and level 1
+# of the style heads; 1x1: the projection shortcuts):
 #   'f16x3' : fp16 hi/lo operand split, three fp16 MFMAs per K step, fp32 accumulation (fp32-equivalent, 5.3x the fp32 MFMA
 #             rate).  Operands must stay inside the fp16 range; every launch checks that on the device and raises a flag
 #             (`overflowed`), on which the caller repeats its forward with 'fp32'.
@@ -75,7 +76,7 @@ class PackedConv:
         oh = (h + 2 * self.padding - self.k) // self.stride + 1
         ow = (w + 2 * self.padding - self.k) // self.stride + 1
         out = torch.empty([n, self.O, oh, ow], dtype=torch.float32, device=x.device)
-        split = precision == 'f16x3' and self.k == 3          # 1x1 projections (a few MFLOP) stay on the exact fp32 kernel
+        split = precision == 'f16x3'
         prec = abi.SG3_CONV_F16X3 if split else abi.SG3_CONV_FP32
         p = abi.Conv2dParams()
         p.x, p.wPacked, p.out = abi.ptr(x), abi.ptr(self.packed(prec)), abi.ptr(out)
