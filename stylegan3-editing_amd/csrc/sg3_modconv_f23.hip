@@ -55,10 +55,10 @@ unsigned long long* g_f23_stamps = nullptr;
 #endif
 
 // ---- accumulator-register helpers: every register is named literally (template integers spliced into the text) ----
-// layout: a[0:23] current A fragments (fragment f = 2 ky + (hi | lo) in a[4f : 4f+3]), a[24:47] landing buffer of the next A request,
+// layout: a[0:23] / a[24:47] the A fragments of even / odd chunks (fragment f = 2 ky + (hi | lo) in a[AB + 4f : AB + 4f+3], AB = 0 | 24),
 // a[48 + 16 b : 63 + 16 b] the accumulator block of tile row b.
-template <int B, int F> __device__ __forceinline__ void f23_mfma(const v8h& bfrag) {
-    asm volatile("v_mfma_f32_32x32x16_f16 a[%c1:%c2], a[%c3:%c4], %0, a[%c1:%c2]" :: "v"(bfrag), "n"(48 + 16 * B), "n"(63 + 16 * B), "n"(4 * F), "n"(4 * F + 3));
+template <int AB, int B, int F> __device__ __forceinline__ void f23_mfma(const v8h& bfrag) {
+    asm volatile("v_mfma_f32_32x32x16_f16 a[%c1:%c2], a[%c3:%c4], %0, a[%c1:%c2]" :: "v"(bfrag), "n"(48 + 16 * B), "n"(63 + 16 * B), "n"(AB + 4 * F), "n"(AB + 4 * F + 3));
 }
 template <int R> __device__ __forceinline__ void f23_acc_zero() { asm volatile("v_accvgpr_write_b32 a[%c0], 0" :: "n"(R)); }
 template <int R> __device__ __forceinline__ float f23_acc_read() { float v; asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "n"(R)); return v; }
@@ -71,16 +71,16 @@ template <int R> struct F23Seq<R, 0> {
     static __device__ __forceinline__ void read(float*) {}
 };
 // the products of one B fragment (patch row Q) with the filter rows ky = 0..2 -> tile rows Q - ky: lo(A) hi(B), hi(A) lo(B), hi(A) hi(B)
-template <int TN, int Q> __device__ __forceinline__ void f23_mfma_row(const v8h& bh, const v8h& bl) {
-    if constexpr (Q >= 0 && Q < TN)         f23_mfma<(Q >= 0 && Q < TN) ? Q : 0, 1>(bh);
-    if constexpr (Q - 1 >= 0 && Q - 1 < TN) f23_mfma<(Q - 1 >= 0 && Q - 1 < TN) ? Q - 1 : 0, 3>(bh);
-    if constexpr (Q - 2 >= 0 && Q - 2 < TN) f23_mfma<(Q - 2 >= 0 && Q - 2 < TN) ? Q - 2 : 0, 5>(bh);
-    if constexpr (Q >= 0 && Q < TN)         f23_mfma<(Q >= 0 && Q < TN) ? Q : 0, 0>(bl);
-    if constexpr (Q - 1 >= 0 && Q - 1 < TN) f23_mfma<(Q - 1 >= 0 && Q - 1 < TN) ? Q - 1 : 0, 2>(bl);
-    if constexpr (Q - 2 >= 0 && Q - 2 < TN) f23_mfma<(Q - 2 >= 0 && Q - 2 < TN) ? Q - 2 : 0, 4>(bl);
-    if constexpr (Q >= 0 && Q < TN)         f23_mfma<(Q >= 0 && Q < TN) ? Q : 0, 0>(bh);
-    if constexpr (Q - 1 >= 0 && Q - 1 < TN) f23_mfma<(Q - 1 >= 0 && Q - 1 < TN) ? Q - 1 : 0, 2>(bh);
-    if constexpr (Q - 2 >= 0 && Q - 2 < TN) f23_mfma<(Q - 2 >= 0 && Q - 2 < TN) ? Q - 2 : 0, 4>(bh);
+template <int AB, int TN, int Q> __device__ __forceinline__ void f23_mfma_row(const v8h& bh, const v8h& bl) {
+    if constexpr (Q >= 0 && Q < TN)         f23_mfma<AB, (Q >= 0 && Q < TN) ? Q : 0, 1>(bh);
+    if constexpr (Q - 1 >= 0 && Q - 1 < TN) f23_mfma<AB, (Q - 1 >= 0 && Q - 1 < TN) ? Q - 1 : 0, 3>(bh);
+    if constexpr (Q - 2 >= 0 && Q - 2 < TN) f23_mfma<AB, (Q - 2 >= 0 && Q - 2 < TN) ? Q - 2 : 0, 5>(bh);
+    if constexpr (Q >= 0 && Q < TN)         f23_mfma<AB, (Q >= 0 && Q < TN) ? Q : 0, 0>(bl);
+    if constexpr (Q - 1 >= 0 && Q - 1 < TN) f23_mfma<AB, (Q - 1 >= 0 && Q - 1 < TN) ? Q - 1 : 0, 2>(bl);
+    if constexpr (Q - 2 >= 0 && Q - 2 < TN) f23_mfma<AB, (Q - 2 >= 0 && Q - 2 < TN) ? Q - 2 : 0, 4>(bl);
+    if constexpr (Q >= 0 && Q < TN)         f23_mfma<AB, (Q >= 0 && Q < TN) ? Q : 0, 0>(bh);
+    if constexpr (Q - 1 >= 0 && Q - 1 < TN) f23_mfma<AB, (Q - 1 >= 0 && Q - 1 < TN) ? Q - 1 : 0, 2>(bh);
+    if constexpr (Q - 2 >= 0 && Q - 2 < TN) f23_mfma<AB, (Q - 2 >= 0 && Q - 2 < TN) ? Q - 2 : 0, 4>(bh);
 }
 
 // wave priority: 0 none | 1 matrix phase at priority 1 | 2 waves 4-7 at priority 1 throughout (the second-dispatched wave of every SIMD
@@ -184,11 +184,13 @@ modconv_f23_kernel(F23Params p) {
     // block instead of ~600 (in-kernel stamps, profiles/r03_f23_stamps.txt).  The counter is in order, so "all but the N youngest" is
     // exact: N = the loads issued after the group that is needed.
     //
-    // A fragments live in ACCUMULATOR registers that only this file's asm statements name: a[0:23] = the six fragments of the
-    // current chunk (fragment f = 2 ky + (hi | lo) in a[4f : 4f+3]), a[24:47] = the landing buffer of the next request.  A request
-    // leads its landing by a whole iteration (the loads take 2-3 us under this kernel's own traffic); F23_LAND waits for it and moves
-    // it down (24 v_accvgpr_mov).  The compiler never sees these values, so it cannot copy, spill or reuse a register a load is still
-    // in flight to -- which it did, in three different ways, while the fragments were ordinary asm outputs (AUDIT below).
+    // A fragments live in ACCUMULATOR registers that only this file's asm statements name: a[0:23] hold the six fragments of the even
+    // chunks, a[24:47] those of the odd chunks (fragment f = 2 ky + (hi | lo) in a[AB + 4f : AB + 4f+3]); the matrix phase exists
+    // twice, once per set.  A request leads its use by a whole iteration (the loads take 2-3 us under this kernel's own traffic) and
+    // goes to the set that the chunk two back has finished reading; F23_LAND only waits for it (an earlier form kept one "current"
+    // set and moved every request down with 24 v_accvgpr_mov per wave and chunk: 3 % of the kernel's vector issue).  The compiler
+    // never sees these values, so it cannot copy, spill or reuse a register a load is still in flight to -- which it did, in three
+    // different ways, while the fragments were ordinary asm outputs (AUDIT below).
     // The input samples (rb, rsc) stay compiler-allocated outputs of their requests; every wait for them names them as read-write
     // operands, which keeps consumers behind the wait and the registers reserved until then.
     f32x2 rb[8][2];
@@ -202,27 +204,33 @@ modconv_f23_kernel(F23Params p) {
     auto fetch_a = [&](int ch) {
         const unsigned so = aS + (unsigned)ch * CHUNKB;               // wave-uniform
         const unsigned vo = ch < p.nch ? aG : 0x80000000u;            // beyond the last chunk: out of range, answered with zeros
-        asm volatile("s_nop 4\n\t"
-                     "buffer_load_dwordx4 a[24:27], %0, %1, %2 offen\n\t"
-                     "buffer_load_dwordx4 a[28:31], %0, %1, %2 offen offset:1024\n\t"
-                     "buffer_load_dwordx4 a[32:35], %0, %1, %2 offen offset:2048\n\t"
-                     "buffer_load_dwordx4 a[36:39], %0, %1, %3 offen\n\t"
-                     "buffer_load_dwordx4 a[40:43], %0, %1, %3 offen offset:1024\n\t"
-                     "buffer_load_dwordx4 a[44:47], %0, %1, %3 offen offset:2048"
-                     :: "v"(vo), "s"(wd), "s"(so), "s"(so + 3 * FRAG)
-                     : "memory", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39",
-                       "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+        // chunk parity picks the register set: the set of chunk ch was last read by the MFMAs of chunk ch - 2, issued long before
+        if (ch & 1)
+            asm volatile("s_nop 4\n\t"
+                         "buffer_load_dwordx4 a[24:27], %0, %1, %2 offen\n\t"
+                         "buffer_load_dwordx4 a[28:31], %0, %1, %2 offen offset:1024\n\t"
+                         "buffer_load_dwordx4 a[32:35], %0, %1, %2 offen offset:2048\n\t"
+                         "buffer_load_dwordx4 a[36:39], %0, %1, %3 offen\n\t"
+                         "buffer_load_dwordx4 a[40:43], %0, %1, %3 offen offset:1024\n\t"
+                         "buffer_load_dwordx4 a[44:47], %0, %1, %3 offen offset:2048"
+                         :: "v"(vo), "s"(wd), "s"(so), "s"(so + 3 * FRAG)
+                         : "memory", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39",
+                           "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+        else
+            asm volatile("s_nop 4\n\t"
+                         "buffer_load_dwordx4 a[0:3], %0, %1, %2 offen\n\t"
+                         "buffer_load_dwordx4 a[4:7], %0, %1, %2 offen offset:1024\n\t"
+                         "buffer_load_dwordx4 a[8:11], %0, %1, %2 offen offset:2048\n\t"
+                         "buffer_load_dwordx4 a[12:15], %0, %1, %3 offen\n\t"
+                         "buffer_load_dwordx4 a[16:19], %0, %1, %3 offen offset:1024\n\t"
+                         "buffer_load_dwordx4 a[20:23], %0, %1, %3 offen offset:2048"
+                         :: "v"(vo), "s"(wd), "s"(so), "s"(so + 3 * FRAG)
+                         : "memory", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15",
+                           "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23");
     };
-    // wait until all but the N youngest loads have landed, then landing buffer -> current fragments
-#define F23_LAND(N) asm volatile("s_waitcnt vmcnt(" F23_CNT(N) ")\n\t" \
-        "v_accvgpr_mov_b32 a0, a24\n\tv_accvgpr_mov_b32 a1, a25\n\tv_accvgpr_mov_b32 a2, a26\n\tv_accvgpr_mov_b32 a3, a27\n\t" \
-        "v_accvgpr_mov_b32 a4, a28\n\tv_accvgpr_mov_b32 a5, a29\n\tv_accvgpr_mov_b32 a6, a30\n\tv_accvgpr_mov_b32 a7, a31\n\t" \
-        "v_accvgpr_mov_b32 a8, a32\n\tv_accvgpr_mov_b32 a9, a33\n\tv_accvgpr_mov_b32 a10, a34\n\tv_accvgpr_mov_b32 a11, a35\n\t" \
-        "v_accvgpr_mov_b32 a12, a36\n\tv_accvgpr_mov_b32 a13, a37\n\tv_accvgpr_mov_b32 a14, a38\n\tv_accvgpr_mov_b32 a15, a39\n\t" \
-        "v_accvgpr_mov_b32 a16, a40\n\tv_accvgpr_mov_b32 a17, a41\n\tv_accvgpr_mov_b32 a18, a42\n\tv_accvgpr_mov_b32 a19, a43\n\t" \
-        "v_accvgpr_mov_b32 a20, a44\n\tv_accvgpr_mov_b32 a21, a45\n\tv_accvgpr_mov_b32 a22, a46\n\tv_accvgpr_mov_b32 a23, a47\n\ts_nop 1" \
-        ::: "memory", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", \
-            "a19", "a20", "a21", "a22", "a23")
+    // wait until all but the N youngest loads have landed: the fragments requested one iteration ago are in their register set (no
+    // landing copies: even and odd chunks own a set each and the MFMA statements name the set of their chunk)
+#define F23_LAND(N) asm volatile("s_waitcnt vmcnt(" F23_CNT(N) ")" ::: "memory")
     auto fetch_b = [&](int ch) {
         const bool in = ch < p.nch;
         // the chunk's channel offset rides in the VECTOR offset of the scale request: only that is range checked, and channels beyond I
@@ -311,7 +319,8 @@ modconv_f23_kernel(F23Params p) {
     };
     // an M block of pure channel padding (O = 203: channels 224..255 of the fourth tile) stages and synchronises but issues no MFMAs
     const bool active = o0 + mb * 32 < p.O;                                  // wave-uniform
-    auto mfma_chunk = [&](int buf) {
+    auto mfma_chunk = [&](auto aset, int buf) {
+        constexpr int AB = decltype(aset)::value;                                // 0 | 24: register set of this chunk's A fragments
         if (!active) return;
 #if F23_PRIO_MODE == 1
         __builtin_amdgcn_s_setprio(1);
@@ -325,12 +334,12 @@ modconv_f23_kernel(F23Params p) {
         if constexpr ((Q) < TN + 2) { \
             if constexpr ((Q) + 1 < TN + 2) load_b(b1, buf, (Q) + 1); \
             __builtin_amdgcn_sched_barrier(0); \
-            f23_mfma_row<TN, (Q)>(b0.h, b0.l); \
+            f23_mfma_row<AB, TN, (Q)>(b0.h, b0.l); \
             __builtin_amdgcn_sched_barrier(0); \
             if constexpr ((Q) + 1 < TN + 2) { \
                 if constexpr ((Q) + 2 < TN + 2) load_b(b0, buf, (Q) + 2); \
                 __builtin_amdgcn_sched_barrier(0); \
-                    f23_mfma_row<TN, (Q) + 1>(b1.h, b1.l); \
+                    f23_mfma_row<AB, TN, (Q) + 1>(b1.h, b1.l); \
                 __builtin_amdgcn_sched_barrier(0); \
             } \
         }
@@ -344,8 +353,8 @@ modconv_f23_kernel(F23Params p) {
 #endif
     };
 
-    // Chunk body: MFMA loop on chunk ch (B image buf = ch & 1, fragments a[0:23]) and the staging block
-    //   H(k, j) = wait B(k) | stage(k) into the other image | request B(k+1) | land A(j) | request A(j+1)
+    // Chunk body: MFMA loop on chunk ch (B image and A register set ch & 1) and the staging block
+    //   H(k, j) = wait B(k) | stage(k) into the other image | request B(k+1) | wait A(j) | request A(j+1)
     //   waves 0-3 ("early"):  MFMA(ch) | H(ch+1, ch+1) | barrier        -- lands what the NEXT iteration multiplies with
     //   waves 4-7 ("late"):   H(ch+1, ch) | MFMA(ch) | barrier          -- lands what THIS iteration multiplies with
     // so on every SIMD one wave's staging arithmetic runs beside the other's matrix instructions, and every request (A: 6 loads,
@@ -391,7 +400,8 @@ modconv_f23_kernel(F23Params p) {
             fetch_a(ch + 1);
         }
         F23_STAMP(tB);
-        mfma_chunk(buf);
+        // two copies of the matrix phase, one per register set (the accumulators are asm-named registers, not compiler values: no merge cost)
+        if (buf) mfma_chunk(std::integral_constant<int, 24>{}, 1); else mfma_chunk(std::integral_constant<int, 0>{}, 0);
         F23_STAMP(tC);
         if (!late) {
             F23_WAIT_B(6);
