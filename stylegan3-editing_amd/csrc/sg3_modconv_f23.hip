@@ -126,6 +126,10 @@ modconv_f23_kernel(F23Params p) {
         }
 #endif
     }
+#ifdef SG3_F23_STAMPS
+    unsigned long long wgStart, wgLoop = 0, wgTiles = 0;
+    F23_STAMP(wgStart);
+#endif
     for (int tile = tFirst; tile < tEnd; tile += tStep) {
     int bid = tile;
     const int mt = bid % p.mTiles; bid /= p.mTiles;
@@ -435,6 +439,7 @@ modconv_f23_kernel(F23Params p) {
         const unsigned long long rEnd = __builtin_amdgcn_s_memrealtime();
         unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
         o[0] = sPre; o[1] = sMfma; o[2] = sPost; o[3] = sBar; o[4] = tEnd - tStart; o[5] = rEnd - rStart;
+        wgLoop += tEnd - tStart; wgTiles++;
         unsigned long long* o2 = p.stamps + (1u << 22) + ((size_t)blockIdx.x * 8 + wave) * 8;      // second half of the buffer: the staging block's parts
         for (int k = 0; k < 5; k++) o2[k] = sH[k];
     }
@@ -481,6 +486,14 @@ modconv_f23_kernel(F23Params p) {
     if constexpr (TN > 5) finish_row(std::integral_constant<int, (TN > 5 ? 5 : 0)>{});
     if constexpr (TN > 6) finish_row(std::integral_constant<int, (TN > 6 ? 6 : 0)>{});
     __syncthreads();                                        // the next tile's first staging block writes where this exchange was read
+#ifdef SG3_F23_STAMPS
+    if (p.stamps && lane == 0) {        // whole-workgroup clock so far, K-loop share of it, tiles walked
+        unsigned long long now; F23_STAMP(now);
+        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[6] = now - wgStart; o[7] = wgLoop;
+        p.stamps[(1u << 22) + ((size_t)blockIdx.x * 8 + wave) * 8 + 5] = wgTiles;
+    }
+#endif
     }   // tiles of this workgroup
 }
 

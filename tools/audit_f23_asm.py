@@ -2,6 +2,8 @@
 between an inline-asm buffer_load and the inline-asm `s_waitcnt vmcnt` that follows it in the text, no instruction may mention
 the load's destination registers (hipcc treats an asm load's destination as written when the load is ISSUED, so a copy, spill or
 read placed there moves stale data: cdna_hip_programming.md section 5.7 item 1).  Also reports scratch use.
+A linear scan: the pending set is dropped at an unconditional branch (the rotated tile loop places the tile's end in front of its
+head; the requests issued before the loop are waited for at the head, not in the text that follows them).
 
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -Istylegan3-editing_amd/csrc -c stylegan3-editing_amd/csrc/sg3_modconv_f23.hip -save-temps -o /tmp/x.o
     python tools/audit_f23_asm.py sg3_modconv_f23-hip-amdgcn-amd-amdhsa-gfx950.s
@@ -40,6 +42,9 @@ for ln, line in enumerate(text, 1):
         continue
     if in_asm and 's_waitcnt' in code and 'vmcnt' in code:
         pending = {}
+        continue
+    if not in_asm and re.match(r'\s*s_branch\b', code):
+        pending = {}                                       # the text behind an unconditional branch is entered from elsewhere (rotated tile loop)
         continue
     if not in_asm and 'v_accvgpr' in code:
         print(f'{kern}: compiler-generated accumulator-register access at line {ln}: {code.strip()}'); bad += 1
