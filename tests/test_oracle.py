@@ -111,3 +111,24 @@ def test_manifest_counts():
     man = manifest()
     assert man['T1024/num_params'] == 21785091 or man['T1024/num_params'] > 2.1e7
     assert len(man['T1024']) == 114
+
+
+def test_mixed_fp16_forward_rounds_where_the_reference_does():
+    """`oracle.synthesis(mixed_fp16=True)` (the yardstick of the GPU mixed-precision tests; no reference fixture exists for it: the
+    reference's fp16 path needs a GPU): every use_fp16 layer hands on fp16-representable activations, its convolution equals the fp32
+    convolution of the fp16-rounded operands, and the image stays within fp16 rounding of the pinned fp32 forward."""
+    sd, sched = build_oracle_generator('Tmini')
+    assert all(l['use_fp16'] for l in sched['layers'])
+    ws = synth_ws(1, sched['num_ws'], sched['w_dim'], seed=2)
+    img32, feats32 = O.synthesis(sd, sched, ws=ws, return_layers=True)
+    img16, feats16 = O.synthesis(sd, sched, ws=ws, mixed_fp16=True, return_layers=True)
+    for f in feats16[1:]:                                                   # layer outputs (the input features stay fp32)
+        assert np.array_equal(f, f.astype(np.float16).astype(np.float32))
+    assert 0 < maxabs(img16, img32) <= 2e-3 * max(1.0, float(np.abs(img32).max()))
+    # the convolution alone: fp16 operands, fp32 accumulation, fp16 result
+    r = np.random.RandomState(3)
+    x = (r.randn(2, 12, 9, 9) * 3).astype(np.float32); w = r.randn(8, 12, 3, 3).astype(np.float32); s = (r.randn(2, 12) + 1).astype(np.float32)
+    y = O.modulated_conv2d_fp16(x, w, s, demodulate=True, padding=2, input_gain=0.7)
+    assert np.array_equal(y, y.astype(np.float16).astype(np.float32))
+    ref = O.modulated_conv2d(x.astype(np.float16).astype(np.float32), w, s, demodulate=True, padding=2, input_gain=0.7)
+    assert maxabs(y, ref) <= 4e-3 * float(np.abs(ref).max())               # weights rounded to fp16 after modulation + output rounding
