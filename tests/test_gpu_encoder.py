@@ -13,7 +13,8 @@ DEV = 'cuda:0'
 
 @pytest.mark.parametrize('n,ci,co,h,w,k,stride,pad,act', [
     (2, 6, 64, 40, 44, 3, 1, 1, 1), (1, 64, 64, 33, 31, 3, 2, 1, 0), (2, 64, 128, 20, 24, 1, 2, 0, 0), (1, 128, 256, 16, 16, 3, 1, 1, 1),
-    (2, 512, 512, 16, 16, 3, 2, 1, 2), (3, 512, 512, 2, 2, 3, 2, 1, 2), (1, 100, 70, 19, 23, 3, 1, 1, 2), (1, 48, 8192, 9, 9, 3, 2, 1, 2)])
+    (2, 512, 512, 16, 16, 3, 2, 1, 2), (3, 512, 512, 2, 2, 3, 2, 1, 2), (1, 100, 70, 19, 23, 3, 1, 1, 2), (1, 48, 8192, 9, 9, 3, 2, 1, 2),
+    (2, 70, 96, 17, 19, 1, 1, 0, 1), (1, 256, 512, 32, 32, 1, 2, 0, 0), (1, 512, 1024, 16, 20 * 4, 3, 2, 1, 2)])
 def test_conv2d_fused(n, ci, co, h, w, k, stride, pad, act):
     from oracle import oracle as O
     from torch_utils.ops.plain_conv import PackedConv
