@@ -127,10 +127,13 @@ modconv_f23_kernel(F23Params p) {
 #endif
     }
 #ifdef SG3_F23_STAMPS
-    unsigned long long wgStart, wgLoop = 0, wgTiles = 0;
+    unsigned long long wgStart, wgLoop = 0, wgTiles = 0, wgPro = 0, wgEpi = 0, tTop = 0, tLoopEnd = 0;
     F23_STAMP(wgStart);
 #endif
     for (int tile = tFirst; tile < tEnd; tile += tStep) {
+#ifdef SG3_F23_STAMPS
+    F23_STAMP(tTop);
+#endif
     int bid = tile;
     const int mt = bid % p.mTiles; bid /= p.mTiles;
     const int xt = bid % p.xTiles; bid /= p.xTiles;
@@ -439,7 +442,7 @@ modconv_f23_kernel(F23Params p) {
         const unsigned long long rEnd = __builtin_amdgcn_s_memrealtime();
         unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
         o[0] = sPre; o[1] = sMfma; o[2] = sPost; o[3] = sBar; o[4] = tEnd - tStart; o[5] = rEnd - rStart;
-        wgLoop += tEnd - tStart; wgTiles++;
+        wgLoop += tEnd - tStart; wgTiles++; wgPro += tStart - tTop; tLoopEnd = tEnd;
         unsigned long long* o2 = p.stamps + (1u << 22) + ((size_t)blockIdx.x * 8 + wave) * 8;      // second half of the buffer: the staging block's parts
         for (int k = 0; k < 5; k++) o2[k] = sH[k];
     }
@@ -491,6 +494,9 @@ modconv_f23_kernel(F23Params p) {
         unsigned long long now; F23_STAMP(now);
         unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
         o[6] = now - wgStart; o[7] = wgLoop;
+        wgEpi += now - tLoopEnd;
+        p.stamps[(1u << 22) + ((size_t)blockIdx.x * 8 + wave) * 8 + 6] = wgPro;
+        p.stamps[(1u << 22) + ((size_t)blockIdx.x * 8 + wave) * 8 + 7] = wgEpi;
         p.stamps[(1u << 22) + ((size_t)blockIdx.x * 8 + wave) * 8 + 5] = wgTiles;
     }
 #endif

@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
         hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
         hipMemset(stamps, 0, (size_t)2 * stampWgs * 64 * 8);
         double sum[2][4] = {}, hs[2][5] = {}; size_t cnt[2] = {}; std::vector<double> ghz;
-        double wgTotal = 0, wgLoop = 0, wgTiles = 0;
+        double wgTotal = 0, wgLoop = 0, wgTiles = 0, wgPro = 0, wgEpi = 0;
         const int nch = (L.I + 15) / 16;
         for (size_t wg = 0; wg < stampWgs; wg++)
             for (int w = 0; w < 8; w++) {
@@ -68,6 +68,7 @@ int main(int argc, char** argv) {
                 for (int k = 0; k < 5; k++) hs[w >> 2][k] += (double)h[(1u << 22) + (wg * 8 + w) * 8 + k] / nch;
                 cnt[w >> 2]++; ghz.push_back((double)o[4] / (double)o[5] * 0.1);
                 wgTotal += (double)o[6]; wgLoop += (double)o[7]; wgTiles += (double)h[(1u << 22) + (wg * 8 + w) * 8 + 5];
+                wgPro += (double)h[(1u << 22) + (wg * 8 + w) * 8 + 6]; wgEpi += (double)h[(1u << 22) + (wg * 8 + w) * 8 + 7];
             }
         std::sort(ghz.begin(), ghz.end());
         printf("%-20s %8.1f %6zu | %6.0f %6.0f %6.0f %6.0f     | %6.0f %6.0f %6.0f %6.0f     | %.3f\n", L.name, ms / 10 * 1e3, cnt[0] / 4,
@@ -76,8 +77,8 @@ int main(int argc, char** argv) {
         printf("    staging block (wait B | stage | request B | land A | request A): early %5.0f %5.0f %5.0f %5.0f %5.0f   late %5.0f %5.0f %5.0f %5.0f %5.0f\n",
                hs[0][0] / cnt[0], hs[0][1] / cnt[0], hs[0][2] / cnt[0], hs[0][3] / cnt[0], hs[0][4] / cnt[0],
                hs[1][0] / cnt[1], hs[1][1] / cnt[1], hs[1][2] / cnt[1], hs[1][3] / cnt[1], hs[1][4] / cnt[1]);
-        printf("    per tile and wave: %.0f cycles, of which the K loop %.0f (%.1f %%): prologue (first requests, first staging), output transform and stores take the rest\n",
-               wgTotal / wgTiles, wgLoop / wgTiles, 100.0 * wgLoop / wgTotal);
+        printf("    per tile and wave: %.0f cycles, of which the K loop %.0f (%.1f %%), the prologue (tile decode, first requests, first staging) %.0f, the output transform and stores %.0f\n",
+               wgTotal / wgTiles, wgLoop / wgTiles, 100.0 * wgLoop / wgTotal, wgPro / wgTiles, wgEpi / wgTiles);
         fflush(stdout);
     }
     return 0;
