@@ -85,6 +85,7 @@ template <int AB, int TN, int Q> __device__ __forceinline__ void f23_mfma_row(co
 
 // wave priority: 0 none | 1 matrix phase at priority 1 | 2 waves 4-7 at priority 1 throughout (the second-dispatched wave of every SIMD
 // loses the issue arbitration to the older one: its staging block took 3-4x as long; measured -6 % on L5..L9) | 3 staging block at 1
+// | 4 waves 0-3 at priority 1 throughout (as slow as none: L6 2035 vs 1878 us with mode 2)
 #ifndef F23_PRIO_MODE
 #define F23_PRIO_MODE 2
 #endif
@@ -373,6 +374,8 @@ modconv_f23_kernel(F23Params p) {
     const int nch = p.nch;
 #if F23_PRIO_MODE == 2
     if (late) __builtin_amdgcn_s_setprio(1);
+#elif F23_PRIO_MODE == 4
+    if (!late) __builtin_amdgcn_s_setprio(1);
 #elif F23_PRIO_MODE == 3
     __builtin_amdgcn_s_setprio(1);
 #endif
