@@ -247,3 +247,34 @@ def test_run_on_batch_survives_weight_updates_after_graph_capture():
         eager = run_on_batch(x, net, opts, sh.avg_image)                                   # the average image of the NEW weights
     assert (a, b) == (0, 3) and lat.is_cuda
     assert maxabs(lat.cpu().numpy(), np.stack([eager[1][i][2] for i in range(3)])) <= 1e-5 * max(1.0, float(np.abs(eager[1][0][2]).max()))
+
+
+@pytest.mark.parametrize('with_transforms', [False, True])
+def test_sharded_inversion_ragged_batches_match_the_eager_loop(with_transforms):
+    """ShardedInversion.invert on 5 frames at batch size 2: two full batches replay the captured ReStyle step (latents stay on the
+    device, the encoder's range flag is read once after them), the ragged last frame runs the eager loop; every frame's latent
+    equals the per-frame eager run_on_batch result (reference inversion/video/inference_on_video.py:119-145 inverts frame by frame),
+    with and without per-frame landmark transforms."""
+    from sg3_runtime.sharded import ShardedInversion
+    from utils.inference_utils import run_on_batch
+    net, opts, *_ = build_restyle_pair('Rmini', device=DEV, n_iters=3)
+    frames = torch.from_numpy(_frames(5, seed=11))
+    lts = None
+    if with_transforms:
+        r = np.random.RandomState(5)
+        lts = torch.from_numpy(np.stack([np.array([[np.cos(a), -np.sin(a), tx], [np.sin(a), np.cos(a), ty], [0, 0, 1]], dtype=np.float32)
+                                         for a, tx, ty in zip(r.uniform(-0.2, 0.2, 5), r.uniform(-0.1, 0.1, 5), r.uniform(-0.1, 0.1, 5))]))
+    with torch.no_grad():
+        sh = ShardedInversion(net, opts, batch_size=2)
+        assert net.graphed_step is not None and net.graphed_step.batch == 2
+        lat, span = sh.invert(frames, lts)
+        assert span == (0, 5) and tuple(lat.shape)[0] == 5 and lat.is_cuda
+        keep, net.graphed_step = net.graphed_step, None                 # the eager loop, frame by frame
+        try:
+            for i in range(5):
+                lt = None if lts is None else lts[i:i + 1].to(DEV)
+                _, ref = run_on_batch(frames[i:i + 1].to(DEV), net, opts, sh.avg_image, landmarks_transform=lt)
+                want = ref[0][-1]
+                assert maxabs(lat[i].cpu().numpy(), want) <= 2e-5 * max(1.0, float(np.abs(want).max())), i
+        finally:
+            net.graphed_step = keep
