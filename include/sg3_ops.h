@@ -321,6 +321,12 @@ enum {
 /* 1 when sg3_modulated_conv2d takes this call with precision SG3_CONV_F16X3_F23 (host-only query, no launch) */
 SG3_API int sg3_modconv_f23_supported(int dtype, int I, int O, int H, int W, int k, int pad, int outRowStride);
 
+/* Diagnostic: force the rows-per-wave of the SG3_CONV_F16X3_F23 kernel (4 | 5 | 7; 0 = the launcher's own cost model, the default)
+ * for every later launch of the process; returns the previous setting.  The tile height fixes the order of a tile's sums, so it is a
+ * process setting made by an explicit call (tests walk all three heights; tools/ A/B runs) -- not an environment variable read per
+ * launch, which could differ between a graph capture and a later eager call.  The environment variable SG3_F23_TN seeds it once. */
+SG3_API int sg3_modconv_f23_force_rows(int rows);
+
 /* number of floats (4-byte units) of the packed weight buffer for an [O,I,k,k] weight
  * (fp32: [O][ceil(I/KC)][k*k][KC] floats; f16x3 / f16: [O][chunks][k*k][hi|lo][16] halfs, chunks = ceil(I/16), rounded up to even for k = 1; zero padded). */
 SG3_API int64_t sg3_modconv_packed_floats(int O, int I, int k, int precision);

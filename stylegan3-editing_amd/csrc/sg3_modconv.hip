@@ -1458,6 +1458,8 @@ int sg3_modconv_f23_supported(int dtype, int I, int O, int H, int W, int k, int 
     return sg3::f23_supported(dtype, I, O, H, W, k, pad, outRowStride) ? 1 : 0;
 }
 
+int sg3_modconv_f23_force_rows(int rows) { return sg3::f23_force_rows(rows); }
+
 int sg3_modulated_conv2d_prep_batch(const sg3_modconv_prep_params* list, int count, void* stream) {
     using namespace sg3;
     SG3_REQUIRE(list && count > 0, "modulated_conv2d_prep_batch: empty list");

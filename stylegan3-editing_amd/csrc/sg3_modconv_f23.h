@@ -9,6 +9,7 @@ int64_t f23_packed_floats(int O, int I);
 // shapes the kernel takes: 3x3, fp32 tensors, even W / pad / row pitch (8-byte column pairs), 32-bit offsets
 bool f23_supported(int dtype, int I, int O, int H, int W, int k, int pad, int outRowStride);
 int launch_conv_f23(const sg3_modconv_params& q, hipStream_t st);
+int f23_force_rows(int rows);          // 4 | 5 | 7, 0 = cost model; returns the previous setting (sg3_modconv_f23_force_rows)
 
 // Packing of one output channel's filters (one workgroup per output channel, called from the prep kernels):
 //   [M tile = o / 64][chunk][M block = (o / 32) % 2][xi][ky][hi|lo][lane][8 halfs],  lane = 32 (c / 8) + o % 32,  element = c % 8

@@ -30,6 +30,7 @@
 #include "sg3_split.h"
 #include "sg3_modconv_f23.h"
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -89,6 +90,11 @@ template <int AB, int TN, int Q> __device__ __forceinline__ void f23_mfma_row(co
 #ifndef F23_PRIO_MODE
 #define F23_PRIO_MODE 2
 #endif
+// staging arithmetic: 0 = single-issue fp32 (round 4), 1 = the packed-fp32 form of round 3 (kept for the same-box A/B only)
+#ifndef F23_STAGE_PACKED
+#define F23_STAGE_PACKED 0
+#endif
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
 
 template <int TN>
 __global__ void __launch_bounds__(512, 2)
@@ -166,9 +172,16 @@ modconv_f23_kernel(F23Params p) {
         const int gy = y0 - p.pad + srow, gx = x0 - p.pad + 2 * spair;
         const bool rowOk = sOk && (unsigned)gy < (unsigned)p.H;
         g0 = rowOk && (unsigned)gx < (unsigned)p.W ? (unsigned)(gy * p.W + gx) * 4u : 0x80000000u;
+#if F23_STAGE_PACKED
         // every sample is requested ONCE: a thread loads its own column pair; the pair to its right arrives from the next lane
         // through DPP, and only the last pair of a tile row (lane 15 of its 16) requests the two halo columns itself
         g1 = rowOk && spair == 15 && (unsigned)(gx + 2) < (unsigned)p.W ? (unsigned)(gy * p.W + gx + 2) * 4u : 0x80000000u;
+#else
+        // a thread requests its own column pair and the pair to its right (the neighbour's own pair: an L1 hit of the same
+        // instruction's lines): the same 16 requests per chunk as a form that passes the neighbour's pair through DPP and lets only
+        // the last lane of a row fetch its halo pair, but without the 16 v_mov_b32_dpp per thread and chunk
+        g1 = rowOk && (unsigned)(gx + 2) < (unsigned)p.W ? (unsigned)(gy * p.W + gx + 2) * 4u : 0x80000000u;
+#endif
     }
     const unsigned gS = (unsigned)(lane & 15) * 4u;                   // style scales: lane c requests channel c of the chunk
     const int sL = srow * 256 + spair * 16 + sch * PLANE;             // + (xi * 2 + part) * 2 * PLANE
@@ -202,9 +215,17 @@ modconv_f23_kernel(F23Params p) {
     // The input samples (rb, rsc) stay compiler-allocated outputs of their requests; every wait for them names them as read-write
     // operands, which keeps consumers behind the wait and the registers reserved until then.
     f32x2 rb[8][2];
+#if F23_STAGE_PACKED
     float rsc;
     constexpr int NB = 17, NA = 6;                                    // loads per input request / per fragment request
-#define F23_CNT(N) #N
+#define F23_NB 17
+#else
+    u32x8 rsc;                                                        // the chunk's eight style scales of this wave's channel half: scalar registers
+    constexpr int NB = 16, NA = 6;
+#define F23_NB 16
+#endif
+#define F23_CNT_(N) #N
+#define F23_CNT(N) F23_CNT_(N)
     // Each request is ONE asm statement that opens with "s_nop 4": hipcc may reload a spilled SGPR with v_readlane right in front
     // of the statement, and an SGPR written by a VALU instruction needs 5 wait states before a vector-memory instruction reads it
     // (descriptor or scalar offset) -- the compiler pads that hazard for its own instructions, not for ones inside an asm string.
@@ -241,15 +262,16 @@ modconv_f23_kernel(F23Params p) {
 #define F23_LAND(N) asm volatile("s_waitcnt vmcnt(" F23_CNT(N) ")" ::: "memory")
     auto fetch_b = [&](int ch) {
         const bool in = ch < p.nch;
-        // the chunk's channel offset rides in the VECTOR offset of the scale request: only that is range checked, and channels beyond I
-        // must read a zero scale (they alias channel 0 of the input)
-        const unsigned v0 = in ? g0 : 0x80000000u, v1 = in ? g1 : 0x80000000u, vs = in ? gS + (unsigned)ch * 64u : 0x80000000u;
         unsigned cf[8];
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             const int ci = ch * 16 + sch * 8 + c;                       // wave-uniform
             cf[c] = ci < p.I ? (unsigned)ci * HWb : 0u;                 // padded channels alias channel 0 and meet a zero scale
         }
+#if F23_STAGE_PACKED
+        // the chunk's channel offset rides in the VECTOR offset of the scale request: only that is range checked, and channels beyond I
+        // must read a zero scale (they alias channel 0 of the input)
+        const unsigned v0 = in ? g0 : 0x80000000u, v1 = in ? g1 : 0x80000000u, vs = in ? gS + (unsigned)ch * 64u : 0x80000000u;
         asm volatile("s_nop 4\n\t"
                      "buffer_load_dword %0, %9, %10, 0 offen\n\t"
                      "buffer_load_dwordx2 %1, %11, %13, %14 offen\n\t"
@@ -262,6 +284,26 @@ modconv_f23_kernel(F23Params p) {
                      "buffer_load_dwordx2 %8, %12, %13, %17 offen"
                      : "=&v"(rsc), "=&v"(rb[0][0]), "=&v"(rb[0][1]), "=&v"(rb[1][0]), "=&v"(rb[1][1]), "=&v"(rb[2][0]), "=&v"(rb[2][1]), "=&v"(rb[3][0]), "=&v"(rb[3][1])
                      : "v"(vs), "s"(sd), "v"(v0), "v"(v1), "s"(xd), "s"(cf[0]), "s"(cf[1]), "s"(cf[2]), "s"(cf[3]) : "memory");
+#else
+        // the eight style scales of (chunk, channel half) arrive through the SCALAR cache, straight into scalar registers (a vector load
+        // + v_readlane per channel costs 15-29 cycles per readlane beside the partner wave's matrix instructions, profiles/r04_mfma_valu_coissue.txt);
+        // the descriptor covers this sample's I scales and the range check is per dword: channels beyond I (they alias channel 0 of the
+        // input) and chunks beyond the last read zeros
+        const unsigned v0 = in ? g0 : 0x80000000u, v1 = in ? g1 : 0x80000000u;
+        const unsigned ss = (unsigned)(ch * 16 + sch * 8) * 4u;        // wave-uniform
+        asm volatile("s_nop 4\n\t"
+                     "s_buffer_load_dwordx8 %0, %9, %10\n\t"
+                     "buffer_load_dwordx2 %1, %11, %13, %14 offen\n\t"
+                     "buffer_load_dwordx2 %2, %12, %13, %14 offen\n\t"
+                     "buffer_load_dwordx2 %3, %11, %13, %15 offen\n\t"
+                     "buffer_load_dwordx2 %4, %12, %13, %15 offen\n\t"
+                     "buffer_load_dwordx2 %5, %11, %13, %16 offen\n\t"
+                     "buffer_load_dwordx2 %6, %12, %13, %16 offen\n\t"
+                     "buffer_load_dwordx2 %7, %11, %13, %17 offen\n\t"
+                     "buffer_load_dwordx2 %8, %12, %13, %17 offen"
+                     : "=&s"(rsc), "=&v"(rb[0][0]), "=&v"(rb[0][1]), "=&v"(rb[1][0]), "=&v"(rb[1][1]), "=&v"(rb[2][0]), "=&v"(rb[2][1]), "=&v"(rb[3][0]), "=&v"(rb[3][1])
+                     : "s"(sd), "s"(ss), "v"(v0), "v"(v1), "s"(xd), "s"(cf[0]), "s"(cf[1]), "s"(cf[2]), "s"(cf[3]) : "memory");
+#endif
         asm volatile("s_nop 4\n\t"
                      "buffer_load_dwordx2 %0, %8, %10, %11 offen\n\t"
                      "buffer_load_dwordx2 %1, %9, %10, %11 offen\n\t"
@@ -276,14 +318,22 @@ modconv_f23_kernel(F23Params p) {
     };
     // AUDIT after every edit (tools/audit_f23_asm.py on the -save-temps .s): between a hand-issued load and the wait that covers it
     // hipcc must not read or copy the destination registers (it treats them as written when the load is issued).
+#if F23_STAGE_PACKED
 #define F23_WAIT_B(N) asm volatile("s_waitcnt vmcnt(" F23_CNT(N) ")" : "+v"(rsc), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]), \
         "+v"(rb[3][0]), "+v"(rb[3][1]), "+v"(rb[4][0]), "+v"(rb[4][1]), "+v"(rb[5][0]), "+v"(rb[5][1]), "+v"(rb[6][0]), "+v"(rb[6][1]), "+v"(rb[7][0]), "+v"(rb[7][1]) :: "memory")
-    static_assert(NB == 17 && NA == 6, "the wait counts below are written for these request sizes");
+#else
+    // the scalar request shares its counter with the LDS instructions and may return out of order: lgkmcnt(0) (nothing else of this
+    // wave is in flight there when a staging block starts)
+#define F23_WAIT_B(N) asm volatile("s_waitcnt vmcnt(" F23_CNT(N) ") lgkmcnt(0)" : "+s"(rsc), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]), \
+        "+v"(rb[3][0]), "+v"(rb[3][1]), "+v"(rb[4][0]), "+v"(rb[4][1]), "+v"(rb[5][0]), "+v"(rb[5][1]), "+v"(rb[6][0]), "+v"(rb[6][1]), "+v"(rb[7][0]), "+v"(rb[7][1]) :: "memory")
+#endif
+    static_assert(NB == F23_NB && NA == 6, "the wait counts below are written for these request sizes");
 
     auto stage = [&](int buf) {
         // Per channel: t = s (d2, d3);  (V0, V3) = s (d0, d1) - t;  (V1, V2) = (s d1 + t.x, t.x - s d1): three packed instructions
         // (the style scale rides in the multiplies; halves picked with op_sel).  Per transform point and channel pair: hi = the two
         // values truncated to fp16 (v_cvt_pkrtz), lo = fp16(value - hi) by v_fma_mixlo / mixhi: three more.
+#if F23_STAGE_PACKED
         f32x2 v03[8], v12[8];
 #pragma unroll
         for (int c = 0; c < 8; c++) {
@@ -299,14 +349,33 @@ modconv_f23_kernel(F23Params p) {
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(v03[c]) : "v"(rb[c][0]), "s"(sc2), "v"(t));
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] neg_hi:[1,0,0]" : "=v"(v12[c]) : "v"(rb[c][0]), "s"(sc2), "v"(t));
         }
+#define F23_V(T, C) ((T) == 0 ? v03[C].x : ((T) == 1 ? v12[C].x : ((T) == 2 ? v12[C].y : v03[C].y)))
+#else
+        // SINGLE-ISSUE fp32 instructions only, each spelled as asm so that hipcc's SLP vectoriser cannot pair them into v_pk_*_f32:
+        // packed fp32 is the one vector class that does not execute beside the SIMD's other wave's matrix instructions (each costs
+        // its full ~10 cycles of matrix-pipe time), v_mul / v_fma / v_cvt_pkrtz / v_fma_mix vanish there (tools/microbench_coissue.hip,
+        // profiles/r04_mfma_valu_coissue.txt).  Same arithmetic as the packed form: t = s d2|3 rounded, then one fma per value.
+        float vt[4][8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const unsigned sc = rsc[c];
+            float t2, t3;
+            asm("v_mul_f32 %0, %1, %2" : "=v"(t2) : "s"(sc), "v"(rb[c][1].x));
+            asm("v_mul_f32 %0, %1, %2" : "=v"(t3) : "s"(sc), "v"(rb[c][1].y));
+            asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(vt[0][c]) : "v"(rb[c][0].x), "s"(sc), "v"(t2));     // V0 = s d0 - s d2
+            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(vt[1][c]) : "v"(rb[c][0].y), "s"(sc), "v"(t2));      // V1 = s d1 + s d2
+            asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(vt[2][c]) : "v"(rb[c][0].y), "s"(sc), "v"(t2));     // V2 = s d2 - s d1
+            asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(vt[3][c]) : "v"(rb[c][0].y), "s"(sc), "v"(t3));     // V3 = s d1 - s d3
+        }
+#define F23_V(T, C) vt[T][C]
+#endif
         unsigned char* dst = sm + buf * BUF + sL;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             u32x4 hv, lv;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const float x0 = t == 0 ? v03[2 * c].x : (t == 1 ? v12[2 * c].x : (t == 2 ? v12[2 * c].y : v03[2 * c].y));
-                const float x1 = t == 0 ? v03[2 * c + 1].x : (t == 1 ? v12[2 * c + 1].x : (t == 2 ? v12[2 * c + 1].y : v03[2 * c + 1].y));
+                const float x0 = F23_V(t, 2 * c), x1 = F23_V(t, 2 * c + 1);
                 const unsigned h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
                 unsigned l;
                 asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=&v"(l) : "v"(h), "v"(x0));
@@ -384,7 +453,7 @@ modconv_f23_kernel(F23Params p) {
     F23_WAIT_B(0);                                                           // everything, A(0) included
     stage(0);
     fetch_b(1);
-    if (!late) { F23_LAND(17); fetch_a(1); }                                 // the late waves land A(0) in their first H
+    if (!late) { F23_LAND(F23_NB); fetch_a(1); }                                 // the late waves land A(0) in their first H
     __syncthreads();
 #ifdef SG3_F23_STAMPS
     unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, sPre = 0, sMfma = 0, sPost = 0, sBar = 0, tStart, rStart;
@@ -405,7 +474,7 @@ modconv_f23_kernel(F23Params p) {
             F23_STAMP(h2);
             fetch_b(ch + 2);
             F23_STAMP(h3);
-            F23_LAND(17);
+            F23_LAND(F23_NB);
             F23_STAMP(h4);
             fetch_a(ch + 1);
         }
@@ -420,7 +489,7 @@ modconv_f23_kernel(F23Params p) {
             F23_STAMP(h2);
             fetch_b(ch + 2);
             F23_STAMP(h3);
-            F23_LAND(17);
+            F23_LAND(F23_NB);
             F23_STAMP(h4);
             fetch_a(ch + 2);
         }
@@ -517,8 +586,10 @@ bool f23_supported(int dtype, int I, int O, int H, int W, int k, int pad, int ou
     if (outH <= 0 || outW <= 0) return false;
     const long long pitch = outRowStride > 0 ? outRowStride : outW;
     if ((pitch & 1) != 0) return false;
-    // every store offset a lane can form (padded channels included) stays below 2^31
-    if ((long long)(ceil_div(O, 64) * 64 + 32) * outH * pitch * 4 >= 0x7fffffffLL) return false;
+    // every store offset a lane can form (padded channels included) stays below 2^31 -- also on the 128-byte aligned row pitch the
+    // inference path may choose AFTER the weights were packed in this kernel's order (the plan-time query passes outRowStride = 0)
+    const long long worst = std::max<long long>(pitch, (outW + 31) / 32 * 32);
+    if ((long long)(ceil_div(O, 64) * 64 + 32) * outH * worst * 4 >= 0x7fffffffLL) return false;
     if ((long long)I * H * W * 4 >= 0x7fffffffLL) return false;
     if ((long long)ceil_div(O, 64) * ceil_div(I, 16) * 49152 >= 0x7fffffffLL) return false;
     return true;
@@ -542,8 +613,20 @@ static int launch_f23(const sg3_modconv_params& q, hipStream_t st) {
     p.stamps = g_f23_stamps;
 #endif
     auto kern = modconv_f23_kernel<TN>;
-    SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-    static const int cus = [] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+    // per device, once: the CU count (grid of persistent workgroups) and this instantiation's dynamic-LDS limit
+    struct DevState { int cus; bool attr; };
+    static DevState devs[64] = {};
+    int dev = 0;
+    SG3_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { set_error("modulated_conv2d: device index %d out of range", dev); return SG3_BAD_ARG; }
+    DevState& ds = devs[dev];
+    if (!ds.attr) {
+        SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+        int n = 0;
+        ds.cus = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        ds.attr = true;
+    }
+    const int cus = ds.cus;
 #ifdef SG3_F23_ONE_TILE
     const unsigned grid = (unsigned)total;
 #else
@@ -554,10 +637,13 @@ static int launch_f23(const sg3_modconv_params& q, hipStream_t st) {
     return SG3_OK;
 }
 
+// forced rows per wave: seeded ONCE from the environment (SG3_F23_TN), changed only by an explicit sg3_modconv_f23_force_rows call
+static std::atomic<int> g_f23_rows{[] { const char* fe = getenv("SG3_F23_TN"); const int v = fe ? atoi(fe) : 0; return (v == 4 || v == 5 || v == 7) ? v : 0; }()};
+int f23_force_rows(int rows) { return g_f23_rows.exchange((rows == 4 || rows == 5 || rows == 7) ? rows : 0); }
+
 int launch_conv_f23(const sg3_modconv_params& q, hipStream_t st) {
     // rows per wave: one workgroup per CU, so the time goes with (rounds of 256 workgroups) x (rows per wave + per-chunk overhead)
-    const char* fe = getenv("SG3_F23_TN");                 // A/B timing and tests: 4 | 5 | 7 rows per wave (read per call)
-    const int forced = fe ? atoi(fe) : 0;
+    const int forced = g_f23_rows.load(std::memory_order_relaxed);          // sg3_modconv_f23_force_rows (tests, A/B timing); 0 = cost model
     const int outH = q.H + 2 * q.pad - 2, outW = q.W + 2 * q.pad - 2;
     const long long per = (long long)q.N * ceil_div(q.O, 64) * ceil_div(outW, 32);
     int best = 7; double bestCost = 1e300;

@@ -119,11 +119,14 @@ class _StyleHeadEncoder(Module):
         # period is even and > sw, so every image starts on an even column (stride 2 keeps each image's own pixel parity) and finds
         # its zero padding in the gap.  Output column (period/2)*i + ox is pixel ox of image i (one junk column per image for even sw).
         period = sw + 2 - (sw & 1)
-        if pk.get('strip_key') != (n, ci, sh, sw, x.device):
-            pk['strip'] = torch.zeros([1, ci, sh, period * n], dtype=torch.float32, device=x.device)
-            pk['strip_key'] = (n, ci, sh, sw, x.device)
-        pk['strip'][0].view(ci, sh, n, period)[..., :sw].copy_(x.permute(1, 2, 0, 3))
-        h = pk['head0'].run(pk['strip'])                                                              # [1, heads*C, oh, (period/2)*N]
+        # One strip per (batch, map shape, device), NEVER replaced while this pack lives: a captured ReStyle graph bakes the strip's
+        # address and relies on its gap columns staying zero, so an eager call at another batch size (the ragged tail of a video,
+        # run_on_batch(x[:2])) must not hand that block back to the allocator.  GraphedReStyleStep pins the whole pack besides.
+        strip = pk.setdefault('strips', {}).get((n, ci, sh, sw, x.device))
+        if strip is None:
+            strip = pk['strips'][(n, ci, sh, sw, x.device)] = torch.zeros([1, ci, sh, period * n], dtype=torch.float32, device=x.device)
+        strip[0].view(ci, sh, n, period)[..., :sw].copy_(x.permute(1, 2, 0, 3))
+        h = pk['head0'].run(strip)                                                                    # [1, heads*C, oh, (period/2)*N]
         oh, ow = (sh + 1) // 2, (sw + 1) // 2
         src = h[0].view(heads, c, oh, n, period // 2)[..., :ow].permute(0, 3, 1, 2, 4)                # [heads, N, C, oh, ow] view
         slope = 1.0                                                                                   # level 1 leaves the kernel activated

@@ -30,6 +30,37 @@ def _cached_inference_tensors(synthesis):
     return modulated_conv.cached_weight_tensors() + networks_stylegan3.derived_tensors(synthesis)
 
 
+def _tensors_in(obj, out, seen):
+    """Every tensor reachable from `obj` through dicts / lists / tuples / plain objects (PackedConv and friends)."""
+    if id(obj) in seen or obj is None or isinstance(obj, (str, bytes, int, float, bool, torch.device, torch.dtype)):
+        return out
+    seen.add(id(obj))
+    if isinstance(obj, torch.Tensor):
+        out.append(obj)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _tensors_in(v, out, seen)
+    elif isinstance(obj, (list, tuple, set)):
+        for v in obj:
+            _tensors_in(v, out, seen)
+    elif hasattr(obj, '__dict__') and not isinstance(obj, torch.nn.Module):
+        _tensors_in(vars(obj), out, seen)
+    return out
+
+
+def _encoder_pack_tensors(encoder):
+    """Everything the encoder's captured kernels read besides parameters and buffers: the packed / folded convolution weights of
+    the trunk units and heads, the permuted GEMM operands of the head levels, the strip images.  `invalidate_packed()` (train() /
+    eval(), .to(), load_state_dict hooks) drops the encoder's references to them; a graph that holds these keeps replaying against
+    live memory whose contents still match the unchanged weights (a weight CHANGE is what is_stale() reports)."""
+    out, seen = [], set()
+    _tensors_in(getattr(encoder, '_packed', None), out, seen)
+    for m in encoder.modules():
+        if m is not encoder:
+            _tensors_in(getattr(m, '_packed', None), out, seen)
+    return out
+
+
 class GraphedSynthesis:
     def __init__(self, generator, batch, all_s_template=None, warmup=2, **synthesis_kwargs):
         """generator: a Generator (or anything with .synthesis / .num_ws / .w_dim) on a CUDA device."""
@@ -145,7 +176,7 @@ class GraphedReStyleStep:
         finally:
             G.synthesis.input.transform = user_transform
         self._fingerprint = self._weights_fingerprint()
-        self._pinned = _cached_inference_tensors(self.net.decoder.synthesis)
+        self._pinned = _cached_inference_tensors(self.net.decoder.synthesis) + _encoder_pack_tensors(self.net.encoder)
 
     def _weights_fingerprint(self):
         G = self.net.decoder
@@ -163,9 +194,11 @@ class GraphedReStyleStep:
         image = net.decoder.synthesis(codes, noise_mode='const', force_fp32=True)
         return image, codes, net.face_pool(image)
 
-    def __call__(self, frames, prev_image, prev_latent):
-        """Returns (image [B,3,R,R], latent [B,n_styles,512], image pooled to 256^2): static tensors, overwritten by the next replay."""
-        if self.is_stale():
+    def __call__(self, frames, prev_image, prev_latent, checked=False):
+        """Returns (image [B,3,R,R], latent [B,n_styles,512], image pooled to 256^2): static tensors, overwritten by the next replay.
+        `checked=True`: the caller has just asked is_stale() itself (run_on_batch does once per batch, not once per step: the
+        fingerprint walks ~700 tensors in Python)."""
+        if not checked and self.is_stale():
             raise RuntimeError('GraphedReStyleStep: encoder / generator weights changed since capture; build a new one '
                                '(is_stale() tells beforehand; run_on_batch falls back to the eager loop)')
         self.frames.copy_(frames, non_blocking=True)

@@ -122,6 +122,7 @@ EXPORTS = [
     ('sg3_modconv_packed_floats', ctypes.c_int64, [ctypes.c_int] * 4),
     ('sg3_modulated_conv2d', ctypes.c_int, [ctypes.POINTER(ModconvParams), c_vp]),
     ('sg3_modconv_f23_supported', ctypes.c_int, [ctypes.c_int] * 8),
+    ('sg3_modconv_f23_force_rows', ctypes.c_int, [ctypes.c_int]),
     ('sg3_fourier_features', ctypes.c_int, [ctypes.POINTER(FourierParams), c_vp]),
     ('sg3_input_transform', ctypes.c_int, [ctypes.POINTER(InputTransformParams), c_vp]),
     ('sg3_affine_batch', ctypes.c_int, [ctypes.POINTER(AffineBatchParams), c_vp]),

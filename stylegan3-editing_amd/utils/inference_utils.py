@@ -102,7 +102,7 @@ def _run_on_batch_graphed(inputs, net, opts, avg_image, landmarks_transform, gra
     prev_latent = net.latent_avg.to(inputs.device)
     images, latents = [], []
     for it in range(steps):
-        image, latent, pooled = graphed(inputs, prev_image, prev_latent)
+        image, latent, pooled = graphed(inputs, prev_image, prev_latent, checked=True)      # run_on_batch asked is_stale() for this batch
         if not final_latents_only:
             if landmarks_transform is not None and it == steps - 1:
                 y_hat = net._render(latent, landmarks_transform.float(), False)

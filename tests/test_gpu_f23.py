@@ -25,20 +25,18 @@ class _f23:
         self.mode, self.tn = mode, tn
 
     def __enter__(self):
+        from torch_utils import _sg3abi as abi
         from torch_utils.ops import modulated_conv as mc
-        self.prev, self.prev_tn = mc.f23, os.environ.get('SG3_F23_TN')
+        self.prev = mc.f23
         mc.f23 = self.mode
-        if self.tn is not None:
-            os.environ['SG3_F23_TN'] = str(self.tn)
+        self.prev_tn = abi.load().sg3_modconv_f23_force_rows(self.tn or 0)
         return mc
 
     def __exit__(self, *exc):
+        from torch_utils import _sg3abi as abi
         from torch_utils.ops import modulated_conv as mc
         mc.f23 = self.prev
-        if self.prev_tn is None:
-            os.environ.pop('SG3_F23_TN', None)
-        else:
-            os.environ['SG3_F23_TN'] = self.prev_tn
+        abi.load().sg3_modconv_f23_force_rows(self.prev_tn)
 
 
 def _took_f23(mc, x, w, pad):

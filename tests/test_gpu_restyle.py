@@ -278,3 +278,42 @@ def test_sharded_inversion_ragged_batches_match_the_eager_loop(with_transforms):
                 assert maxabs(lat[i].cpu().numpy(), want) <= 2e-5 * max(1.0, float(np.abs(want).max())), i
         finally:
             net.graphed_step = keep
+
+
+def test_graph_replay_after_a_ragged_tail_and_after_eval_reads_live_memory():
+    """ADVICE r3 (high / medium): the captured ReStyle step bakes the addresses of the encoder's strip image and packed weights.
+    (i) An eager call at another batch size (the ragged tail of invert(), run_on_batch(x[:1])) must not replace the strip the graph
+    replays into; (ii) `net.eval()` / `invalidate_packed()` after the capture drops the encoder's references to its packs while
+    is_stale() stays False (no weight changed), so the graph must hold them itself.  Both: invert -> eager odd batch -> (eval,
+    empty_cache, allocations that would reuse freed blocks) -> invert again == the per-frame eager loop."""
+    from sg3_runtime.sharded import ShardedInversion
+    from utils.inference_utils import run_on_batch
+    net, opts, *_ = build_restyle_pair('Rmini', device=DEV, n_iters=3)
+    frames = torch.from_numpy(_frames(5, seed=23))
+    with torch.no_grad():
+        sh = ShardedInversion(net, opts, batch_size=2)
+        g = net.graphed_step
+        assert g is not None and g.batch == 2
+        first, _ = sh.invert(frames)                                    # two replays, then the ragged frame eagerly (batch 1: another strip)
+        first = first.clone()
+        run_on_batch(frames[:1].to(DEV), net, opts, sh.avg_image)       # one more eager call at batch 1
+        net.eval()                                                      # -> invalidate_packed(): the encoder forgets its packs
+        assert net.encoder._packed is None and not g.is_stale()
+        run_on_batch(frames[:1].to(DEV), net, opts, sh.avg_image)       # re-packs (new tensors, new strips)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        junk = [torch.full([1 << 20], float('nan'), device=DEV) for _ in range(64)]     # anything freed would be reused and poisoned here
+        assert net.graphed_step is g
+        second, _ = sh.invert(frames)
+        torch.cuda.synchronize()
+        del junk
+        assert torch.isfinite(second).all()
+        assert maxabs(second.cpu().numpy(), first.cpu().numpy()) <= 1e-6
+        keep, net.graphed_step = net.graphed_step, None
+        try:
+            for i in range(5):
+                _, ref = run_on_batch(frames[i:i + 1].to(DEV), net, opts, sh.avg_image)
+                want = ref[0][-1]
+                assert maxabs(second[i].cpu().numpy(), want) <= 2e-5 * max(1.0, float(np.abs(want).max())), i
+        finally:
+            net.graphed_step = keep

@@ -1,6 +1,6 @@
 """Audit of the hand-issued loads of modconv_f23_kernel in the compiler's output (hipcc -save-temps .s):
 between an inline-asm buffer_load and the inline-asm `s_waitcnt vmcnt` that follows it in the text, no instruction may mention
-the load's destination registers (hipcc treats an asm load's destination as written when the load is ISSUED, so a copy, spill or
+the load's destination registers (vector registers of buffer_load, scalar registers of s_buffer_load until an asm lgkmcnt(0)) (hipcc treats an asm load's destination as written when the load is ISSUED, so a copy, spill or
 read placed there moves stale data: cdna_hip_programming.md section 5.7 item 1).  Also reports scratch use.
 A linear scan: the pending set is dropped at an unconditional branch (the rotated tile loop places the tile's end in front of its
 head; the requests issued before the loop are waited for at the head, not in the text that follows them).
@@ -14,12 +14,13 @@ import sys
 text = open(sys.argv[1]).read().split('\n')
 kern = None
 bad = 0
-pending = {}          # register number -> line of the load
+pending = {}          # vector register number -> line of the load
+spending = {}         # scalar register number -> line of the scalar-cache load (s_buffer_load into SGPRs, round 4)
 in_asm = False
 for ln, line in enumerate(text, 1):
     m = re.match(r'^(_ZN3sg318modconv_f23_kernel\w+):', line)
     if m:
-        kern, pending = m.group(1), {}
+        kern, pending, spending = m.group(1), {}, {}
     if kern is None:
         continue
     if 's_endpgm' in line:
@@ -40,17 +41,36 @@ for ln, line in enumerate(text, 1):
         for r in range(lo, hi + 1):
             pending[r] = ln
         continue
-    if in_asm and 's_waitcnt' in code and 'vmcnt' in code:
-        pending = {}
+    if in_asm and 's_buffer_load' in code:
+        d = re.search(r's_buffer_load_\w+\s+s\[(\d+):(\d+)\]|s_buffer_load_\w+\s+s(\d+)', code)
+        lo, hi = (int(d.group(1)), int(d.group(2))) if d.group(1) else (int(d.group(3)), int(d.group(3)))
+        for r in range(lo, hi + 1):
+            spending[r] = ln
+        continue
+    if in_asm and 's_waitcnt' in code:
+        if 'vmcnt' in code:
+            pending = {}
+        if 'lgkmcnt(0)' in code:
+            spending = {}
         continue
     if not in_asm and re.match(r'\s*s_branch\b', code):
-        pending = {}                                       # the text behind an unconditional branch is entered from elsewhere (rotated tile loop)
+        pending, spending = {}, {}                         # the text behind an unconditional branch is entered from elsewhere (rotated tile loop)
         continue
     if not in_asm and 'v_accvgpr' in code:
         print(f'{kern}: compiler-generated accumulator-register access at line {ln}: {code.strip()}'); bad += 1
     if 'scratch_' in code:
         print(f'{kern}: scratch access at line {ln}: {code.strip()}'); bad += 1
-    if not pending or not code.strip() or code.strip().startswith('.'):
+    if not code.strip() or code.strip().startswith('.'):
+        continue
+    if spending:
+        sregs = set()
+        for a, b in re.findall(r'\bs\[(\d+):(\d+)\]', code):
+            sregs.update(range(int(a), int(b) + 1))
+        sregs.update(int(r) for r in re.findall(r'\bs(\d+)\b', code))
+        hit = sorted(r for r in sregs if r in spending)
+        if hit:
+            print(f'{kern}: line {ln} touches s{hit} loaded at line {spending[hit[0]]} before its wait: {code.strip()}'); bad += 1
+    if not pending:
         continue
     regs = set()
     for a, b in re.findall(r'v\[(\d+):(\d+)\]', code):

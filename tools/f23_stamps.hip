@@ -14,7 +14,7 @@ namespace sg3 { void set_error(const char* fmt, ...) { va_list a; va_start(a, fm
 struct Layer { const char* name; int I, O, H; };
 
 int main(int argc, char** argv) {
-    if (argc > 1) setenv("SG3_F23_TN", argv[1], 1);
+    if (argc > 1) sg3::f23_force_rows(atoi(argv[1]));
     const int N = 8;
     const Layer layers[] = {{"L5 512->512 @84", 512, 512, 84}, {"L6 512->512 @148", 512, 512, 148}, {"L8 323->203 @276", 323, 203, 276}, {"L9 203->128 @532", 203, 128, 532}};
     size_t maxIn = 0, maxOut = 0, maxW = 0;
