@@ -91,6 +91,9 @@ template <int AB, int TN, int Q> __device__ __forceinline__ void f23_mfma_row(co
 #define F23_PRIO_MODE 2
 #endif
 // staging arithmetic: 0 = single-issue fp32 (round 4), 1 = the packed-fp32 form of round 3 (kept for the same-box A/B only)
+#ifndef F23_AGPR_PROBE
+#define F23_AGPR_PROBE 0
+#endif
 #ifndef F23_STAGE_PACKED
 #define F23_STAGE_PACKED 0
 #endif
@@ -506,7 +509,16 @@ modconv_f23_kernel(F23Params p) {
     // until they have landed: the wait names them.  (An operand-less s_waitcnt here let hipcc reuse them for the epilogue's addresses
     // before the wait, and the returning zeros overwrote those.)  The matrix instructions were issued from asm statements: the
     // compiler does not know their latency, so the accumulators are given the wait states an XDL result needs before they are read.
+#if F23_AGPR_PROBE == 1
+    fetch_a(nch + 2 + (nch & 1));                                            // probe: out-of-range request for a[0:23] IN FRONT of the closing wait
+#endif
     F23_WAIT_B(0);
+#if F23_AGPR_PROBE == 2
+    fetch_a(nch + 2 + (nch & 1));                                            // probe: the same request BEHIND the closing wait (round 3: NaN everywhere)
+#elif F23_AGPR_PROBE == 3
+    fetch_a(nch + 2 + (nch & 1));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 #ifdef SG3_F23_STAMPS
     if (p.stamps && lane == 0) {

@@ -1,7 +1,9 @@
 """Audit of the hand-issued loads of modconv_f23_kernel in the compiler's output (hipcc -save-temps .s):
 between an inline-asm buffer_load and the inline-asm `s_waitcnt vmcnt` that follows it in the text, no instruction may mention
 the load's destination registers (vector registers of buffer_load, scalar registers of s_buffer_load until an asm lgkmcnt(0)) (hipcc treats an asm load's destination as written when the load is ISSUED, so a copy, spill or
-read placed there moves stale data: cdna_hip_programming.md section 5.7 item 1).  Also reports scratch use.
+read placed there moves stale data: cdna_hip_programming.md section 5.7 item 1).  Also reports scratch use, compiler-generated accumulator-register
+accesses, and compiler-COUNTED vmcnt waits (N > 0) issued while hand-issued loads are still in flight (the compiler's count does not
+include them, so such a wait can release a consumer early).
 A linear scan: the pending set is dropped at an unconditional branch (the rotated tile loop places the tile's end in front of its
 head; the requests issued before the loop are waited for at the head, not in the text that follows them).
 
@@ -16,11 +18,12 @@ kern = None
 bad = 0
 pending = {}          # vector register number -> line of the load
 spending = {}         # scalar register number -> line of the scalar-cache load (s_buffer_load into SGPRs, round 4)
+apending = 0          # line of the last hand-issued load into accumulator registers that no asm vmcnt wait has covered yet
 in_asm = False
 for ln, line in enumerate(text, 1):
     m = re.match(r'^(_ZN3sg318modconv_f23_kernel\w+):', line)
     if m:
-        kern, pending, spending = m.group(1), {}, {}
+        kern, pending, spending, apending = m.group(1), {}, {}, 0
     if kern is None:
         continue
     if 's_endpgm' in line:
@@ -33,10 +36,11 @@ for ln, line in enumerate(text, 1):
         in_asm = False
         continue
     code = line.split(';')[0]
-    if in_asm and 'buffer_load' in code:
+    if in_asm and 'buffer_load' in code and 's_buffer_load' not in code:
         d = re.search(r'buffer_load_\w+\s+v\[(\d+):(\d+)\]|buffer_load_\w+\s+v(\d+)', code)
         if d is None:
-            continue                                       # destination in the accumulator file: not compiler-visible
+            apending = ln                                  # destination in the accumulator file: not compiler-visible, but IN FLIGHT
+            continue
         lo, hi = (int(d.group(1)), int(d.group(2))) if d.group(1) else (int(d.group(3)), int(d.group(3)))
         for r in range(lo, hi + 1):
             pending[r] = ln
@@ -49,13 +53,20 @@ for ln, line in enumerate(text, 1):
         continue
     if in_asm and 's_waitcnt' in code:
         if 'vmcnt' in code:
-            pending = {}
+            pending, apending = {}, 0
         if 'lgkmcnt(0)' in code:
             spending = {}
         continue
     if not in_asm and re.match(r'\s*s_branch\b', code):
-        pending, spending = {}, {}                         # the text behind an unconditional branch is entered from elsewhere (rotated tile loop)
+        pending, spending, apending = {}, {}, 0            # the text behind an unconditional branch is entered from elsewhere (rotated tile loop)
         continue
+    if not in_asm and (pending or apending):
+        # the compiler counts only the loads IT issued: a counted wait of its own (vmcnt(N), N > 0) while hand-issued loads are in
+        # flight behind it lets N of ITS loads... in fact N loads of the whole queue stay out: its consumer may read a register that
+        # has not landed.  (vmcnt(0) over-waits, which is only slow.)
+        w = re.search(r's_waitcnt.*vmcnt\((\d+)\)', code)
+        if w and int(w.group(1)) > 0:
+            print(f'{kern}: line {ln}: compiler-counted {code.strip()} while hand-issued loads (line {apending or min(pending.values())}) are in flight'); bad += 1
     if not in_asm and 'v_accvgpr' in code:
         print(f'{kern}: compiler-generated accumulator-register access at line {ln}: {code.strip()}'); bad += 1
     if 'scratch_' in code:
