@@ -247,8 +247,17 @@ def bench_inversion(G, device, rank, world, frames_per_gpu=16, restyle_steps=5, 
         fl_ms = timer.median_step_ms('filtered_lrelu', len(fl_layers))
         gbs = fl_bytes / (fl_ms * 1e-3) / 1e9 if fl_ms > 0 else 0.0
         radial = any(getattr(G.synthesis, nm).down_radial for nm in fl_layers)
+        # PMC traffic of the same launches (tools/sum_traffic.py over `tools/time_config.py R1024 --batch 16`), quoted only for the
+        # kernel source and batch it was collected on
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'flrelu_traffic_R.json')
+        if radial and frames_per_gpu == 16 and os.path.exists(tfile):
+            with open(tfile) as f:
+                tj = json.load(f)
+            if tj.get('kernel_source_sha') == kernel_source_sha():
+                traffic = tj['traffic_bytes_per_step']
         roofline = {'bound': 'hbm', 'kernel': 'flrelu_stream_kernel' + (' (radial 12x12 down filters)' if radial else ''), 'achieved': gbs, 'peak': HBM_PEAK_GBS,
-                    'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_bytes_per_forward': fl_bytes,
+                    'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': traffic, 'algorithmic_bytes_per_forward': fl_bytes,
                     'kernel_ms_per_forward': fl_ms, 'batch': frames_per_gpu}
         timer.reset()
     return dict(metric='ReStyle-pSp video-inversion frames/sec', value=n_frames * reps / float(t.item()), unit='frames/s',

@@ -76,11 +76,12 @@ def _f23_wanted(ci, co, h, wd, padding):
     thin layers (few K chunks per tile, HBM-bound) and narrow planes stay on the direct kernel."""
     if f23 == 'on':
         return True
-    # measured at FFHQ-1024 config T, batch 8 (tools/bench_layer.py, same box): L3 / L4 (512 -> 512 @ 54^2 / 86^2) 445 -> 346 us, L5 953 -> 814,
-    # L6 2450 -> 1921, L7 (512 -> 323) 1702 -> 1516, L8 (323 -> 203) 2310 -> 2015, L9 (203 -> 128) 856 -> 729; the thin layers lose:
-    # L10 (128 -> 81: 8 chunks per tile) 1415 -> 1483, L11 2439 -> 2393 (a tie), and the 38-column planes of L0-L2 fill 59 % of two column tiles
+    # measured at FFHQ-1024 config T, batch 8 (tools/bench_layer.py, same box, round 4 = staging on single-issue fp32): L3 328 -> 307 us
+    # against round 3's kernel (direct kernel: 429), L5 791 -> 718, L6 1799 -> 1653-1713, L7 1454 -> 1263-1326, L8 1839 -> 1705,
+    # L9 695 -> 627; since then the thin layers gain too: L10 (128 -> 81: 8 chunks per tile) 1527 direct -> 1398, L11 (81 -> 51) 2453 ->
+    # 2293; L12 (51 -> 32: 4 chunks, half an M tile) loses, 1014 -> 1456, and the 38-column planes of L0-L2 fill 59 % of two column tiles
     ow = wd + 2 * padding - 2
-    return ci >= 192 and co >= 96 and ow >= 48
+    return ci * co >= 4000 and co >= 48 and ow >= 48
 
 
 class _Prepared:

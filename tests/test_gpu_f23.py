@@ -155,3 +155,41 @@ def test_f23_many_tiles_per_workgroup():
         with _f23('on', tn) as mc:
             y = mc.modulated_conv2d(T(x), T(wt), T(s), demodulate=True, padding=2, x_bound=8.0)
         assert maxabs(y.cpu().numpy(), ref) <= 5e-6 * float(np.abs(ref).max()), tn
+
+
+@pytest.mark.parametrize('ci,co,h', [(512, 512, 84), (323, 203, 60)])
+def test_f23_data_gradient_at_layer_shapes_matches_fp64(ci, co, h):
+    """the transform-domain kernel ALSO runs the data gradient of the PTI step (pad-0 form, transposed + flipped
+    effective weights, per-sample scale vectors exchanged).  Here at real layer shapes -- 512 -> 512 with an 86^2 gradient (L5 of
+    T-1024, N = 1) and 323 -> 203 (L8's channel counts: padded K chunk, an M block of pure padding) -- against the fp64 oracle:
+    dx = J^T dy with J the reference's grouped convolution (networks_stylegan3.py:39-62), evaluated as the oracle's convolution of
+    dy with the transposed, flipped effective weights, at the forward tolerance (5e-6 relative)."""
+    from oracle import oracle as O
+    x = np.clip(rand(91, 1, ci, h, h) * 40, -256, 256).astype(np.float32)
+    wt = rand(92, co, ci, 3, 3); s = (rand(93, 1, ci) + 1).astype(np.float32)
+    dy = (rand(94, 1, co, h + 2, h + 2) * 3).astype(np.float32)
+    gain = 0.8
+    with _f23('on') as mc:
+        xt = T(x).requires_grad_(True)
+        y = mc.modulated_conv2d(xt, T(wt), T(s), demodulate=True, padding=2, input_gain=torch.tensor(gain, device=DEV), x_bound=256.0)
+        from torch_utils import _sg3abi as abi
+        # the backward's convolution: I and O exchanged, the (h + 2)^2 gradient as its input, pad 0
+        assert abi.load().sg3_modconv_f23_supported(abi.SG3_F32, co, ci, h + 2, h + 2, 3, 0, 0) == 1 and mc._f23_wanted(co, ci, h + 2, h + 2, 0)
+        before = abi.launch_count
+        (dx,) = torch.autograd.grad(y, xt, T(dy))
+        assert abi.launch_count > before
+    # fp64 effective weights of the single sample (reference :39-56), then the adjoint of the pad-2 correlation
+    w64, s64 = wt.astype(np.float64), s.astype(np.float64)
+    wn = w64 / np.sqrt(np.mean(np.square(w64), axis=(1, 2, 3), keepdims=True))
+    sn = s64 / np.sqrt(np.mean(np.square(s64)))
+    we = wn * sn[0][None, :, None, None]
+    we = we / np.sqrt(np.sum(np.square(we), axis=(1, 2, 3), keepdims=True) + 1e-8) * gain                      # [O,I,3,3]
+    wadj = np.ascontiguousarray(we[:, :, ::-1, ::-1].transpose(1, 0, 2, 3))                                         # [I,O,3,3]
+    ref = O.modulated_conv2d(dy.astype(np.float64), wadj, np.ones([1, co]), False, 0, None)                        # [1,I,h,h]
+    assert ref.shape == tuple(dx.shape)
+    err = maxabs(dx.cpu().numpy(), ref) / max(1.0, float(np.abs(ref).max()))
+    print(f'data gradient {co} -> {ci} @ {h + 2}^2, relative max error vs fp64: {err:.2e}')
+    assert err <= 5e-6, err
+    # and the forward of the same call, for completeness of the pair
+    fref = O.modulated_conv2d(x.astype(np.float64), w64, s64, True, 2, gain)
+    assert maxabs(y.detach().cpu().numpy(), fref) <= 5e-6 * max(1.0, float(np.abs(fref).max()))

@@ -17,17 +17,24 @@ by = {}
 for r in rows:
     by.setdefault(int(r['Dispatch_Id']), {'name': r['Kernel_Name']})[r['Counter_Name']] = float(r['Counter_Value'])
 dur = {int(r['Dispatch_Id']): (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in csv.DictReader(open(sys.argv[2]))}
-disp = [(k, v) for k, v in sorted(by.items()) if 'flrelu_stream' in v['name']][-14:]
-assert len(disp) == 14
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _last_forward import flrelu_groups  # noqa: E402
+
+groups = flrelu_groups({k: v['name'] for k, v in by.items()})
 title = sys.argv[3] if len(sys.argv) > 3 else 'T-1024'
-print(f'filtered_lrelu launches of one {title} batch-8 forward (profiled pass: clocks read 3-5 % below an un-profiled run)')
-print(f"{'layer':5s} {'kernel':22s} {'us':>8s} {'GHz':>5s} {'VALU insts M':>13s} {'VALU issue util':>16s} {'waves/SIMD':>11s} {'wait_any':>9s} {'wait_inst':>10s}")
+n_launch = sum(len(d) for _, d in groups)
+print(f'filtered_lrelu launches of one {title} forward: {n_launch} launches for 14 layers (profiled pass: clocks read 3-5 % below an un-profiled run)')
+print(f"{'layer':22s} {'kernel':22s} {'us':>8s} {'GHz':>5s} {'VALU insts M':>13s} {'VALU issue util':>16s} {'waves/SIMD':>11s} {'wait_any':>9s} {'wait_inst':>10s}")
 tv = ta = 0.0
-for j, (k, d) in enumerate(disp):
-    us, act = dur[k], d['GRBM_GUI_ACTIVE'] / 8
-    iv, av, wc = d['SQ_INSTS_VALU'], d['SQ_ACTIVE_INST_VALU'], d['SQ_WAVE_CYCLES']
-    tv += av * 4 / 1024; ta += act
-    kern = d['name'][d['name'].index('<'):d['name'].index('>') + 1]
-    print(f"L{j:<4d} {kern:22s} {us:8.1f} {act / us / 1e3:5.2f} {iv / 1e6:13.1f} {av * 4 / 1024 / act:16.2f} {wc * 4 / 1024 / act:11.2f} "
-          f"{d['SQ_WAIT_ANY'] / wc:9.2f} {d['SQ_WAIT_INST_ANY'] / wc:10.2f}")
-print(f'all 14 launches: VALU issue utilisation {tv / ta:.2f} at the clock each launch ran at')
+for lab, ids in groups:
+    for j, k in enumerate(ids):
+        d = by[k]
+        us, act = dur[k], d['GRBM_GUI_ACTIVE'] / 8
+        iv, av, wc = d['SQ_INSTS_VALU'], d['SQ_ACTIVE_INST_VALU'], d['SQ_WAVE_CYCLES']
+        tv += av * 4 / 1024; ta += act
+        kern = d['name'][d['name'].index('<'):d['name'].index('>') + 1]
+        name = lab if len(ids) == 1 else lab + (' full strips' if j == 0 else ' remainder strips')
+        print(f"{name:22s} {kern:22s} {us:8.1f} {act / us / 1e3:5.2f} {iv / 1e6:13.1f} {av * 4 / 1024 / act:16.2f} {wc * 4 / 1024 / act:11.2f} "
+              f"{d['SQ_WAIT_ANY'] / wc:9.2f} {d['SQ_WAIT_INST_ANY'] / wc:10.2f}")
+print(f'all {n_launch} launches: VALU issue utilisation {tv / ta:.2f} at the clock each launch ran at')
