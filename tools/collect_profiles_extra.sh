@@ -15,6 +15,12 @@ echo "[1/7] VALU counters of the filtered_lrelu launches, config R-1024 (radial 
 rocprofv3 --kernel-trace --pmc $VALU --output-format csv -d "$OUT/pmcR" -o v -- python3 tools/time_config.py R1024 --batch 8 --iters 2 > "$OUT/pmcR.log" 2> "$OUT/pmcR.err"
 python3 tools/sum_valu.py "$(first $OUT/pmcR/*/v_counter_collection.csv $OUT/pmcR/v_counter_collection.csv)" "$(first $OUT/pmcR/*/v_kernel_trace.csv $OUT/pmcR/v_kernel_trace.csv)" "config R-1024" > "$OUT/configR_valu_pmc.txt"
 rm -rf "$OUT/pmcR"
+# HBM traffic of the radial launches at the inversion batch (16 frames per forward): FETCH_SIZE and WRITE_SIZE in separate passes
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmcRf" -o f -- python3 tools/time_config.py R1024 --batch 16 --iters 2 > /dev/null 2> "$OUT/pmcRf.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmcRw" -o w -- python3 tools/time_config.py R1024 --batch 16 --iters 2 > /dev/null 2> "$OUT/pmcRw.err"
+python3 tools/sum_traffic.py "$(first $OUT/pmcRf/*/f_counter_collection.csv $OUT/pmcRf/f_counter_collection.csv)" "$(first $OUT/pmcRw/*/w_counter_collection.csv $OUT/pmcRw/w_counter_collection.csv)" \
+    "$OUT/flrelu_traffic_R.json" "one batch-16 R1024 forward"
+rm -rf "$OUT/pmcRf" "$OUT/pmcRw"
 rocprofv3 --kernel-trace --pmc $VALU --output-format csv -d "$OUT/pmcT" -o v -- python3 bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline --no-inversion --no-extras > /dev/null 2> "$OUT/pmcT.err"
 python3 tools/sum_valu.py "$(first $OUT/pmcT/*/v_counter_collection.csv $OUT/pmcT/v_counter_collection.csv)" "$(first $OUT/pmcT/*/v_kernel_trace.csv $OUT/pmcT/v_kernel_trace.csv)" > "$OUT/flrelu_valu_pmc.txt"
 rm -rf "$OUT/pmcT"
