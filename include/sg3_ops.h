@@ -316,9 +316,13 @@ enum {
                           * instructions, the same split arithmetic on the transformed operands (inputs transformed in fp32 before
                           * the split, weights at pack time).  3x3 kernels on fp32 tensors with even W, pad and output row pitch
                           * only (sg3_modconv_f23_supported); its own packed layout, so prep and convolution must agree */
+    SG3_CONV_F16_F23 = 4, /* SG3_CONV_F16 in the same transform domain, for fp16 tensors (the reference's `use_fp16` layers,
+                          * networks_stylegan3.py:355-366): transformed inputs and weights rounded to fp16 once, one product per K step,
+                          * fp32 accumulation, fp16 output.  Same shape rules; packed layout without lo fragments (half the size) */
 };
 
-/* 1 when sg3_modulated_conv2d takes this call with precision SG3_CONV_F16X3_F23 (host-only query, no launch) */
+/* 1 when sg3_modulated_conv2d takes this call with precision SG3_CONV_F16X3_F23 (dtype SG3_F32) / SG3_CONV_F16_F23 (dtype SG3_F16)
+ * (host-only query, no launch) */
 SG3_API int sg3_modconv_f23_supported(int dtype, int I, int O, int H, int W, int k, int pad, int outRowStride);
 
 /* Diagnostic: force the rows-per-wave of the SG3_CONV_F16X3_F23 kernel (4 | 5 | 7; 0 = the launcher's own cost model, the default)

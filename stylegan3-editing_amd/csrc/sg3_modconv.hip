@@ -1103,8 +1103,8 @@ static __device__ __forceinline__ void prep_w_body(const sg3_modconv_prep_params
         for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
         scale = rsqrtf(red[0] / (float)len);
     }
-    if (p.precision == SG3_CONV_F16X3_F23) {
-        f23_pack_row(w, scale, o, p.O, p.I, nch, reinterpret_cast<_Float16*>(p.wPacked));      // transform-domain layout (sg3_modconv_f23.h)
+    if (p.precision == SG3_CONV_F16X3_F23 || p.precision == SG3_CONV_F16_F23) {
+        f23_pack_row(w, scale, o, p.O, p.I, nch, reinterpret_cast<_Float16*>(p.wPacked), p.precision == SG3_CONV_F16X3_F23);      // transform-domain layout (sg3_modconv_f23.h)
     } else if (p.precision != SG3_CONV_FP32) {
         // [o][chunk][tap][hi|lo][16] halfs
         _Float16* dsth = reinterpret_cast<_Float16*>(p.wPacked) + (size_t)o * nch * taps * 32;
@@ -1192,7 +1192,7 @@ static __device__ __forceinline__ void prep_s_body(const sg3_modconv_prep_params
         const float peak = red[0] * (p.xBoundDev ? p.xBoundDev[0] : p.xBound);
         int e = 0;
         if (peak > 0.f && peak < 3.0e38f) e = (int)ceilf(log2f(peak / 32768.f));    // either direction: tiny operands (gradients) are scaled up
-        if (p.precision == SG3_CONV_F16X3_F23) e += 1;                               // the input transform forms sums of two samples
+        if (p.precision == SG3_CONV_F16X3_F23 || p.precision == SG3_CONV_F16_F23) e += 1;                               // the input transform forms sums of two samples
         down = ldexpf(1.f, -e); up = ldexpf(1.f, e);
     }
     __syncthreads();
@@ -1428,7 +1428,7 @@ extern "C" {
 
 int64_t sg3_modconv_packed_floats(int O, int I, int k, int precision) {
     if (O <= 0 || I <= 0 || (k != 1 && k != 3)) return 0;
-    if (precision == SG3_CONV_F16X3_F23) return k == 3 ? sg3::f23_packed_floats(O, I) : 0;
+    if (precision == SG3_CONV_F16X3_F23 || precision == SG3_CONV_F16_F23) return k == 3 ? sg3::f23_packed_floats(O, I, precision == SG3_CONV_F16X3_F23) : 0;
     if (precision == SG3_CONV_F16X3 || precision == SG3_CONV_F16) {
         return (int64_t)O * sg3::f16x3_chunks(I, k) * (k * k) * 16;   // 32 halfs = 16 floats per (chunk, tap)
     }
@@ -1445,9 +1445,9 @@ static int prep_validate(const sg3_modconv_prep_params* p) {
     SG3_REQUIRE(p->inputGainMode >= 0 && p->inputGainMode <= 3, "modulated_conv2d_prep: bad inputGainMode");
     SG3_REQUIRE(p->inputGainMode == 0 || p->inputGain, "modulated_conv2d_prep: inputGain missing");
     SG3_REQUIRE((size_t)p->I * 2 * sizeof(float) <= 48 * 1024, "modulated_conv2d_prep: too many input channels");
-    SG3_REQUIRE(p->precision == SG3_CONV_FP32 || p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16 || p->precision == SG3_CONV_F16X3_F23,
-                "modulated_conv2d_prep: bad precision");
-    SG3_REQUIRE(p->precision != SG3_CONV_F16X3_F23 || p->k == 3, "modulated_conv2d_prep: the transform-domain form is for 3x3 kernels");
+    SG3_REQUIRE(p->precision == SG3_CONV_FP32 || p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16 || p->precision == SG3_CONV_F16X3_F23 ||
+                p->precision == SG3_CONV_F16_F23, "modulated_conv2d_prep: bad precision");
+    SG3_REQUIRE((p->precision != SG3_CONV_F16X3_F23 && p->precision != SG3_CONV_F16_F23) || p->k == 3, "modulated_conv2d_prep: the transform-domain forms are for 3x3 kernels");
     if (p->precision != SG3_CONV_FP32) {
         SG3_REQUIRE((p->xBound > 0.f || p->xBoundDev) && p->dcoef, "modulated_conv2d_prep: f16x3 needs xBound > 0 and a dcoef buffer");
     }
@@ -1519,16 +1519,19 @@ int sg3_modulated_conv2d(const sg3_modconv_params* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     {
         const int outW = p->W + 2 * p->pad - p->k + 1;
-        const bool rowStream = p->k == 3 && (p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16 || p->precision == SG3_CONV_F16X3_F23);
+        const bool rowStream = p->k == 3 && (p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16 || p->precision == SG3_CONV_F16X3_F23 ||
+                                             p->precision == SG3_CONV_F16_F23);
         SG3_REQUIRE(p->outRowStride == 0 || p->outRowStride == outW || (rowStream && p->outRowStride > outW),
                     "modulated_conv2d: outRowStride must be 0 or outW (a larger pitch is supported by the 3x3 f16x3 / f16 kernels only)");
     }
     const bool torgb = p->precision == SG3_CONV_FP32 && p->k == 1 && p->pad == 0 && p->O <= 4 && (size_t)p->I * 4 * sizeof(float) <= 48 * 1024;
     SG3_REQUIRE(!p->epilogueBias || torgb, "modulated_conv2d: the bias / clamp / scale epilogue exists for the ToRGB kernel only (1x1, O <= 4, fp32 form)");
-    if (p->precision == SG3_CONV_F16X3_F23) {
-        SG3_REQUIRE(p->dcoef, "modulated_conv2d: f16x3 needs dcoef");
+    if (p->precision == SG3_CONV_F16X3_F23 || p->precision == SG3_CONV_F16_F23) {
+        SG3_REQUIRE(p->dcoef, "modulated_conv2d: the transform-domain forms need dcoef");
+        SG3_REQUIRE(p->dtype == (p->precision == SG3_CONV_F16X3_F23 ? SG3_F32 : SG3_F16),
+                    "modulated_conv2d: SG3_CONV_F16X3_F23 takes fp32 tensors, SG3_CONV_F16_F23 fp16 tensors");
         SG3_REQUIRE(f23_supported(p->dtype, p->I, p->O, p->H, p->W, p->k, p->pad, p->outRowStride),
-                    "modulated_conv2d: SG3_CONV_F16X3_F23 takes 3x3 kernels on fp32 tensors with even W, pad and row pitch (sg3_modconv_f23_supported)");
+                    "modulated_conv2d: the transform-domain forms take 3x3 kernels with even W, pad and row pitch (sg3_modconv_f23_supported)");
         return launch_conv_f23(*p, st);
     }
     if (p->precision == SG3_CONV_F16X3 || p->precision == SG3_CONV_F16) {

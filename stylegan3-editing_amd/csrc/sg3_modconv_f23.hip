@@ -40,7 +40,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct F23Params {
-    const float* x; const void* wp; const float* sIn; const float* dcoef; float* out;
+    const void* x; const void* wp; const float* sIn; const float* dcoef; void* out;
     int N, I, O, H, W, outH, outW, pad;
     int nch, xTiles, yTiles, mTiles, totalBlocks, outPitch;
 #ifdef SG3_F23_STAMPS
@@ -84,29 +84,37 @@ template <int AB, int TN, int Q> __device__ __forceinline__ void f23_mfma_row(co
     if constexpr (Q - 2 >= 0 && Q - 2 < TN) f23_mfma<AB, (Q - 2 >= 0 && Q - 2 < TN) ? Q - 2 : 0, 4>(bh);
 }
 
+// fp16 operand form (SG3_CONV_F16_F23): operands rounded once, ONE product per filter row; fragment ky in a[AB + 4 ky : AB + 4 ky + 3]
+template <int AB, int TN, int Q> __device__ __forceinline__ void f23_mfma_row_f16(const v8h& b) {
+    if constexpr (Q >= 0 && Q < TN)         f23_mfma<AB, (Q >= 0 && Q < TN) ? Q : 0, 0>(b);
+    if constexpr (Q - 1 >= 0 && Q - 1 < TN) f23_mfma<AB, (Q - 1 >= 0 && Q - 1 < TN) ? Q - 1 : 0, 1>(b);
+    if constexpr (Q - 2 >= 0 && Q - 2 < TN) f23_mfma<AB, (Q - 2 >= 0 && Q - 2 < TN) ? Q - 2 : 0, 2>(b);
+}
+
 // wave priority: 0 none | 1 matrix phase at priority 1 | 2 waves 4-7 at priority 1 throughout (the second-dispatched wave of every SIMD
 // loses the issue arbitration to the older one: its staging block took 3-4x as long; measured -6 % on L5..L9) | 3 staging block at 1
 // | 4 waves 0-3 at priority 1 throughout (as slow as none: L6 2035 vs 1878 us with mode 2)
+// Round 4 (single-issue staging): modes 0 / 1 / 2 and three per-phase schemes measure within the run-to-run spread of each other
+// (profiles/r04_f23_prio.txt); 2 stays.
 #ifndef F23_PRIO_MODE
 #define F23_PRIO_MODE 2
 #endif
-// staging arithmetic: 0 = single-issue fp32 (round 4), 1 = the packed-fp32 form of round 3 (kept for the same-box A/B only)
-#ifndef F23_AGPR_PROBE
-#define F23_AGPR_PROBE 0
-#endif
-#ifndef F23_STAGE_PACKED
-#define F23_STAGE_PACKED 0
-#endif
 typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
 
-template <int TN>
+// T = float: split precision (SG3_CONV_F16X3_F23, fp32 tensors); T = _Float16: the fp16 operand form (SG3_CONV_F16_F23, fp16 tensors:
+// the reference's `use_fp16` layers, networks_stylegan3.py:355-366) -- operands rounded to fp16 once, one product per K step, no lo
+// planes / fragments, fp16 stores.  Same work split, staging map, request / wait structure and output transform.
+template <int TN, typename T>
 __global__ void __launch_bounds__(512, 2)
 modconv_f23_kernel(F23Params p) {
+    constexpr bool SPLIT = sizeof(T) == 4;
+    constexpr int EB = (int)sizeof(T);
+    constexpr int NF = SPLIT ? 6 : 3;                  // A fragments per (chunk, M block, xi): 3 ky x (hi | lo)  |  3 ky
     constexpr int PR = 2 * TN + 2;                     // patch rows of a tile
     constexpr int PLANE = PR * 256;                    // bytes per (xi, part, channel half) plane: rows of 16 pairs x 16 B
-    constexpr int BUF = 16 * PLANE;                    // 4 xi x (hi | lo) x 2 channel halves
+    constexpr int BUF = (SPLIT ? 16 : 8) * PLANE;      // 4 xi x (hi | lo) x 2 channel halves  |  4 xi x 2 channel halves
     constexpr int FRAG = 1024;                         // bytes per A fragment (64 lanes x 16 B)
-    constexpr int CHUNKB = 2 * 4 * 6 * FRAG;           // packed weights per (M tile, chunk): 2 M blocks x 4 xi x (3 ky x hi|lo)
+    constexpr int CHUNKB = 2 * 4 * NF * FRAG;          // packed weights per (M tile, chunk): 2 M blocks x 4 xi x fragments
     static_assert(PR <= 16, "staging map: 8 waves x 2 (row, channel half) pairs");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];           // 2 x BUF (>= 64 KB: the exchange area of the output transform)
@@ -151,7 +159,7 @@ modconv_f23_kernel(F23Params p) {
     const int o0 = mt * 64, x0 = xt * 32, y0 = yt * (2 * TN);
 
     // ---- descriptors, as SGPR quads for the hand-issued loads below ----
-    const unsigned HWb = (unsigned)(p.H * p.W) * 4u;
+    const unsigned HWb = (unsigned)(p.H * p.W) * (unsigned)EB;
     auto make_desc = [](const void* base, unsigned bytes) {
         const unsigned long long a = (unsigned long long)base;
         u32x4 d;
@@ -161,7 +169,7 @@ modconv_f23_kernel(F23Params p) {
         d.w = 0x00020000u;
         return d;
     };
-    const u32x4 xd = make_desc(p.x + (size_t)n * p.I * p.H * p.W, (unsigned)p.I * HWb);
+    const u32x4 xd = make_desc(static_cast<const T*>(p.x) + (size_t)n * p.I * p.H * p.W, (unsigned)p.I * HWb);
     const u32x4 wd = make_desc(p.wp, (unsigned)p.mTiles * (unsigned)p.nch * (unsigned)CHUNKB);
     const u32x4 sd = make_desc(p.sIn + (size_t)n * p.I, (unsigned)p.I * 4u);
 
@@ -174,25 +182,18 @@ modconv_f23_kernel(F23Params p) {
     {
         const int gy = y0 - p.pad + srow, gx = x0 - p.pad + 2 * spair;
         const bool rowOk = sOk && (unsigned)gy < (unsigned)p.H;
-        g0 = rowOk && (unsigned)gx < (unsigned)p.W ? (unsigned)(gy * p.W + gx) * 4u : 0x80000000u;
-#if F23_STAGE_PACKED
-        // every sample is requested ONCE: a thread loads its own column pair; the pair to its right arrives from the next lane
-        // through DPP, and only the last pair of a tile row (lane 15 of its 16) requests the two halo columns itself
-        g1 = rowOk && spair == 15 && (unsigned)(gx + 2) < (unsigned)p.W ? (unsigned)(gy * p.W + gx + 2) * 4u : 0x80000000u;
-#else
+        g0 = rowOk && (unsigned)gx < (unsigned)p.W ? (unsigned)(gy * p.W + gx) * (unsigned)EB : 0x80000000u;
         // a thread requests its own column pair and the pair to its right (the neighbour's own pair: an L1 hit of the same
         // instruction's lines): the same 16 requests per chunk as a form that passes the neighbour's pair through DPP and lets only
         // the last lane of a row fetch its halo pair, but without the 16 v_mov_b32_dpp per thread and chunk
-        g1 = rowOk && (unsigned)(gx + 2) < (unsigned)p.W ? (unsigned)(gy * p.W + gx + 2) * 4u : 0x80000000u;
-#endif
+        g1 = rowOk && (unsigned)(gx + 2) < (unsigned)p.W ? (unsigned)(gy * p.W + gx + 2) * (unsigned)EB : 0x80000000u;
     }
-    const unsigned gS = (unsigned)(lane & 15) * 4u;                   // style scales: lane c requests channel c of the chunk
-    const int sL = srow * 256 + spair * 16 + sch * PLANE;             // + (xi * 2 + part) * 2 * PLANE
+    const int sL = srow * 256 + spair * 16 + sch * PLANE;             // + (xi * 2 + part) * 2 * PLANE (split) | + xi * 2 * PLANE (fp16)
     // ---- A: this wave's six fragments of a chunk ----
-    const unsigned aG = (unsigned)((mb * 4 + xi) * 6) * FRAG + (unsigned)lane * 16u;
+    const unsigned aG = (unsigned)((mb * 4 + xi) * NF) * FRAG + (unsigned)lane * 16u;
     const unsigned aS = (unsigned)mt * (unsigned)p.nch * (unsigned)CHUNKB;             // + chunk * CHUNKB + fragment * FRAG (scalar offset)
     // ---- B fragment reads ----
-    const int bR = (xi * 4 + lh) * PLANE + (rg * TN) * 256 + pq * 16;  // hi plane of this lane's channel half; lo at + 2 PLANE
+    const int bR = (xi * (SPLIT ? 4 : 2) + lh) * PLANE + (rg * TN) * 256 + pq * 16;  // (hi) plane of this lane's channel half; split: lo at + 2 PLANE
 
     // the kernel's accumulator-register allocation covers what the asm statements name (the highest register named as a clobber sizes
     // it); the compiler itself stays within its arch VGPRs (AUDIT: no v_accvgpr_* outside the asm statements)
@@ -217,16 +218,11 @@ modconv_f23_kernel(F23Params p) {
     // different ways, while the fragments were ordinary asm outputs (AUDIT below).
     // The input samples (rb, rsc) stay compiler-allocated outputs of their requests; every wait for them names them as read-write
     // operands, which keeps consumers behind the wait and the registers reserved until then.
-    f32x2 rb[8][2];
-#if F23_STAGE_PACKED
-    float rsc;
-    constexpr int NB = 17, NA = 6;                                    // loads per input request / per fragment request
-#define F23_NB 17
-#else
+    typedef typename std::conditional<SPLIT, f32x2, unsigned>::type RB;   // a column pair of one channel: two floats | two halfs
+    RB rb[8][2];
     u32x8 rsc;                                                        // the chunk's eight style scales of this wave's channel half: scalar registers
-    constexpr int NB = 16, NA = 6;
+    constexpr int NB = 16, NA = NF;
 #define F23_NB 16
-#endif
 #define F23_CNT_(N) #N
 #define F23_CNT(N) F23_CNT_(N)
     // Each request is ONE asm statement that opens with "s_nop 4": hipcc may reload a spilled SGPR with v_readlane right in front
@@ -237,6 +233,23 @@ modconv_f23_kernel(F23Params p) {
         const unsigned so = aS + (unsigned)ch * CHUNKB;               // wave-uniform
         const unsigned vo = ch < p.nch ? aG : 0x80000000u;            // beyond the last chunk: out of range, answered with zeros
         // chunk parity picks the register set: the set of chunk ch was last read by the MFMAs of chunk ch - 2, issued long before
+        if constexpr (!SPLIT) {
+            // fp16 form: three fragments (one per filter row) in a[0:11] | a[24:35]
+            if (ch & 1)
+                asm volatile("s_nop 4\n\t"
+                             "buffer_load_dwordx4 a[24:27], %0, %1, %2 offen\n\t"
+                             "buffer_load_dwordx4 a[28:31], %0, %1, %2 offen offset:1024\n\t"
+                             "buffer_load_dwordx4 a[32:35], %0, %1, %2 offen offset:2048"
+                             :: "v"(vo), "s"(wd), "s"(so)
+                             : "memory", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35");
+            else
+                asm volatile("s_nop 4\n\t"
+                             "buffer_load_dwordx4 a[0:3], %0, %1, %2 offen\n\t"
+                             "buffer_load_dwordx4 a[4:7], %0, %1, %2 offen offset:1024\n\t"
+                             "buffer_load_dwordx4 a[8:11], %0, %1, %2 offen offset:2048"
+                             :: "v"(vo), "s"(wd), "s"(so)
+                             : "memory", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11");
+        } else
         if (ch & 1)
             asm volatile("s_nop 4\n\t"
                          "buffer_load_dwordx4 a[24:27], %0, %1, %2 offen\n\t"
@@ -271,114 +284,79 @@ modconv_f23_kernel(F23Params p) {
             const int ci = ch * 16 + sch * 8 + c;                       // wave-uniform
             cf[c] = ci < p.I ? (unsigned)ci * HWb : 0u;                 // padded channels alias channel 0 and meet a zero scale
         }
-#if F23_STAGE_PACKED
-        // the chunk's channel offset rides in the VECTOR offset of the scale request: only that is range checked, and channels beyond I
-        // must read a zero scale (they alias channel 0 of the input)
-        const unsigned v0 = in ? g0 : 0x80000000u, v1 = in ? g1 : 0x80000000u, vs = in ? gS + (unsigned)ch * 64u : 0x80000000u;
-        asm volatile("s_nop 4\n\t"
-                     "buffer_load_dword %0, %9, %10, 0 offen\n\t"
-                     "buffer_load_dwordx2 %1, %11, %13, %14 offen\n\t"
-                     "buffer_load_dwordx2 %2, %12, %13, %14 offen\n\t"
-                     "buffer_load_dwordx2 %3, %11, %13, %15 offen\n\t"
-                     "buffer_load_dwordx2 %4, %12, %13, %15 offen\n\t"
-                     "buffer_load_dwordx2 %5, %11, %13, %16 offen\n\t"
-                     "buffer_load_dwordx2 %6, %12, %13, %16 offen\n\t"
-                     "buffer_load_dwordx2 %7, %11, %13, %17 offen\n\t"
-                     "buffer_load_dwordx2 %8, %12, %13, %17 offen"
-                     : "=&v"(rsc), "=&v"(rb[0][0]), "=&v"(rb[0][1]), "=&v"(rb[1][0]), "=&v"(rb[1][1]), "=&v"(rb[2][0]), "=&v"(rb[2][1]), "=&v"(rb[3][0]), "=&v"(rb[3][1])
-                     : "v"(vs), "s"(sd), "v"(v0), "v"(v1), "s"(xd), "s"(cf[0]), "s"(cf[1]), "s"(cf[2]), "s"(cf[3]) : "memory");
-#else
         // the eight style scales of (chunk, channel half) arrive through the SCALAR cache, straight into scalar registers (a vector load
         // + v_readlane per channel costs 15-29 cycles per readlane beside the partner wave's matrix instructions, profiles/r04_mfma_valu_coissue.txt);
         // the descriptor covers this sample's I scales and the range check is per dword: channels beyond I (they alias channel 0 of the
         // input) and chunks beyond the last read zeros
         const unsigned v0 = in ? g0 : 0x80000000u, v1 = in ? g1 : 0x80000000u;
         const unsigned ss = (unsigned)(ch * 16 + sch * 8) * 4u;        // wave-uniform
-        asm volatile("s_nop 4\n\t"
-                     "s_buffer_load_dwordx8 %0, %9, %10\n\t"
-                     "buffer_load_dwordx2 %1, %11, %13, %14 offen\n\t"
-                     "buffer_load_dwordx2 %2, %12, %13, %14 offen\n\t"
-                     "buffer_load_dwordx2 %3, %11, %13, %15 offen\n\t"
-                     "buffer_load_dwordx2 %4, %12, %13, %15 offen\n\t"
-                     "buffer_load_dwordx2 %5, %11, %13, %16 offen\n\t"
-                     "buffer_load_dwordx2 %6, %12, %13, %16 offen\n\t"
-                     "buffer_load_dwordx2 %7, %11, %13, %17 offen\n\t"
-                     "buffer_load_dwordx2 %8, %12, %13, %17 offen"
-                     : "=&s"(rsc), "=&v"(rb[0][0]), "=&v"(rb[0][1]), "=&v"(rb[1][0]), "=&v"(rb[1][1]), "=&v"(rb[2][0]), "=&v"(rb[2][1]), "=&v"(rb[3][0]), "=&v"(rb[3][1])
-                     : "s"(sd), "s"(ss), "v"(v0), "v"(v1), "s"(xd), "s"(cf[0]), "s"(cf[1]), "s"(cf[2]), "s"(cf[3]) : "memory");
-#endif
-        asm volatile("s_nop 4\n\t"
-                     "buffer_load_dwordx2 %0, %8, %10, %11 offen\n\t"
-                     "buffer_load_dwordx2 %1, %9, %10, %11 offen\n\t"
-                     "buffer_load_dwordx2 %2, %8, %10, %12 offen\n\t"
-                     "buffer_load_dwordx2 %3, %9, %10, %12 offen\n\t"
-                     "buffer_load_dwordx2 %4, %8, %10, %13 offen\n\t"
-                     "buffer_load_dwordx2 %5, %9, %10, %13 offen\n\t"
-                     "buffer_load_dwordx2 %6, %8, %10, %14 offen\n\t"
-                     "buffer_load_dwordx2 %7, %9, %10, %14 offen"
-                     : "=&v"(rb[4][0]), "=&v"(rb[4][1]), "=&v"(rb[5][0]), "=&v"(rb[5][1]), "=&v"(rb[6][0]), "=&v"(rb[6][1]), "=&v"(rb[7][0]), "=&v"(rb[7][1])
-                     : "v"(v0), "v"(v1), "s"(xd), "s"(cf[4]), "s"(cf[5]), "s"(cf[6]), "s"(cf[7]) : "memory");
+        // split: a column pair is 8 bytes (dwordx2); fp16: 4 bytes (dword) -- same sixteen requests, same wait counts
+#define F23_REQ_B(LD) \
+        asm volatile("s_nop 4\n\t" \
+                     "s_buffer_load_dwordx8 %0, %9, %10\n\t" \
+                     LD " %1, %11, %13, %14 offen\n\t" \
+                     LD " %2, %12, %13, %14 offen\n\t" \
+                     LD " %3, %11, %13, %15 offen\n\t" \
+                     LD " %4, %12, %13, %15 offen\n\t" \
+                     LD " %5, %11, %13, %16 offen\n\t" \
+                     LD " %6, %12, %13, %16 offen\n\t" \
+                     LD " %7, %11, %13, %17 offen\n\t" \
+                     LD " %8, %12, %13, %17 offen" \
+                     : "=&s"(rsc), "=&v"(rb[0][0]), "=&v"(rb[0][1]), "=&v"(rb[1][0]), "=&v"(rb[1][1]), "=&v"(rb[2][0]), "=&v"(rb[2][1]), "=&v"(rb[3][0]), "=&v"(rb[3][1]) \
+                     : "s"(sd), "s"(ss), "v"(v0), "v"(v1), "s"(xd), "s"(cf[0]), "s"(cf[1]), "s"(cf[2]), "s"(cf[3]) : "memory"); \
+        asm volatile("s_nop 4\n\t" \
+                     LD " %0, %8, %10, %11 offen\n\t" \
+                     LD " %1, %9, %10, %11 offen\n\t" \
+                     LD " %2, %8, %10, %12 offen\n\t" \
+                     LD " %3, %9, %10, %12 offen\n\t" \
+                     LD " %4, %8, %10, %13 offen\n\t" \
+                     LD " %5, %9, %10, %13 offen\n\t" \
+                     LD " %6, %8, %10, %14 offen\n\t" \
+                     LD " %7, %9, %10, %14 offen" \
+                     : "=&v"(rb[4][0]), "=&v"(rb[4][1]), "=&v"(rb[5][0]), "=&v"(rb[5][1]), "=&v"(rb[6][0]), "=&v"(rb[6][1]), "=&v"(rb[7][0]), "=&v"(rb[7][1]) \
+                     : "v"(v0), "v"(v1), "s"(xd), "s"(cf[4]), "s"(cf[5]), "s"(cf[6]), "s"(cf[7]) : "memory")
+        if constexpr (SPLIT) { F23_REQ_B("buffer_load_dwordx2"); } else { F23_REQ_B("buffer_load_dword"); }
+#undef F23_REQ_B
     };
     // AUDIT after every edit (tools/audit_f23_asm.py on the -save-temps .s): between a hand-issued load and the wait that covers it
     // hipcc must not read or copy the destination registers (it treats them as written when the load is issued).
-#if F23_STAGE_PACKED
-#define F23_WAIT_B(N) asm volatile("s_waitcnt vmcnt(" F23_CNT(N) ")" : "+v"(rsc), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]), \
-        "+v"(rb[3][0]), "+v"(rb[3][1]), "+v"(rb[4][0]), "+v"(rb[4][1]), "+v"(rb[5][0]), "+v"(rb[5][1]), "+v"(rb[6][0]), "+v"(rb[6][1]), "+v"(rb[7][0]), "+v"(rb[7][1]) :: "memory")
-#else
     // the scalar request shares its counter with the LDS instructions and may return out of order: lgkmcnt(0) (nothing else of this
     // wave is in flight there when a staging block starts)
 #define F23_WAIT_B(N) asm volatile("s_waitcnt vmcnt(" F23_CNT(N) ") lgkmcnt(0)" : "+s"(rsc), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]), \
         "+v"(rb[3][0]), "+v"(rb[3][1]), "+v"(rb[4][0]), "+v"(rb[4][1]), "+v"(rb[5][0]), "+v"(rb[5][1]), "+v"(rb[6][0]), "+v"(rb[6][1]), "+v"(rb[7][0]), "+v"(rb[7][1]) :: "memory")
-#endif
-    static_assert(NB == F23_NB && NA == 6, "the wait counts below are written for these request sizes");
+    static_assert(NB == F23_NB && NA == (SPLIT ? 6 : 3), "the wait counts below are written for these request sizes");
+    // "all but the A request's loads": six (split) | three (fp16) younger loads stay out
+#define F23_WAIT_B_NA() do { if constexpr (SPLIT) { F23_WAIT_B(6); } else { F23_WAIT_B(3); } } while (0)
 
     auto stage = [&](int buf) {
-        // Per channel: t = s (d2, d3);  (V0, V3) = s (d0, d1) - t;  (V1, V2) = (s d1 + t.x, t.x - s d1): three packed instructions
-        // (the style scale rides in the multiplies; halves picked with op_sel).  Per transform point and channel pair: hi = the two
-        // values truncated to fp16 (v_cvt_pkrtz), lo = fp16(value - hi) by v_fma_mixlo / mixhi: three more.
-#if F23_STAGE_PACKED
-        f32x2 v03[8], v12[8];
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const unsigned long long sc2 = (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, rsc), sch * 8 + c);   // low half: the scale
-            // columns (2p+2, 2p+3) = the own pair of the lane to the right (row_shl: lane i takes lane i + 1 of its row of 16; the
-            // last lane of a row has no source and keeps what it loaded: the halo pair)
-            float nx = rb[c][1].x, ny = rb[c][1].y;
-            asm("v_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(nx) : "v"(rb[c][0].x));
-            asm("v_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(ny) : "v"(rb[c][0].y));
-            const f32x2 right = {nx, ny};
-            f32x2 t;
-            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(right), "s"(sc2));
-            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(v03[c]) : "v"(rb[c][0]), "s"(sc2), "v"(t));
-            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] neg_hi:[1,0,0]" : "=v"(v12[c]) : "v"(rb[c][0]), "s"(sc2), "v"(t));
-        }
-#define F23_V(T, C) ((T) == 0 ? v03[C].x : ((T) == 1 ? v12[C].x : ((T) == 2 ? v12[C].y : v03[C].y)))
-#else
+        unsigned char* dst = sm + buf * BUF + sL;
+        if constexpr (SPLIT) {
+        // Per channel: t2|3 = s d2|3;  V0 = s d0 - t2,  V1 = s d1 + t2,  V2 = t2 - s d1,  V3 = s d1 - t3 (the style scale rides in the
+        // multiplies).  Per transform point and channel pair: hi = the two values truncated to fp16 (v_cvt_pkrtz), lo = fp16(value - hi)
+        // by v_fma_mixlo / mixhi: three more.
         // SINGLE-ISSUE fp32 instructions only, each spelled as asm so that hipcc's SLP vectoriser cannot pair them into v_pk_*_f32:
         // packed fp32 is the one vector class that does not execute beside the SIMD's other wave's matrix instructions (each costs
         // its full ~10 cycles of matrix-pipe time), v_mul / v_fma / v_cvt_pkrtz / v_fma_mix vanish there (tools/microbench_coissue.hip,
-        // profiles/r04_mfma_valu_coissue.txt).  Same arithmetic as the packed form: t = s d2|3 rounded, then one fma per value.
+        // profiles/r04_mfma_valu_coissue.txt).
         float vt[4][8];
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             const unsigned sc = rsc[c];
+            const float d0 = rb[c][0].x, d1 = rb[c][0].y, d2 = rb[c][1].x, d3 = rb[c][1].y;
             float t2, t3;
-            asm("v_mul_f32 %0, %1, %2" : "=v"(t2) : "s"(sc), "v"(rb[c][1].x));
-            asm("v_mul_f32 %0, %1, %2" : "=v"(t3) : "s"(sc), "v"(rb[c][1].y));
-            asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(vt[0][c]) : "v"(rb[c][0].x), "s"(sc), "v"(t2));     // V0 = s d0 - s d2
-            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(vt[1][c]) : "v"(rb[c][0].y), "s"(sc), "v"(t2));      // V1 = s d1 + s d2
-            asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(vt[2][c]) : "v"(rb[c][0].y), "s"(sc), "v"(t2));     // V2 = s d2 - s d1
-            asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(vt[3][c]) : "v"(rb[c][0].y), "s"(sc), "v"(t3));     // V3 = s d1 - s d3
+            asm("v_mul_f32 %0, %1, %2" : "=v"(t2) : "s"(sc), "v"(d2));
+            asm("v_mul_f32 %0, %1, %2" : "=v"(t3) : "s"(sc), "v"(d3));
+            asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(vt[0][c]) : "v"(d0), "s"(sc), "v"(t2));     // V0 = s d0 - s d2
+            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(vt[1][c]) : "v"(d1), "s"(sc), "v"(t2));      // V1 = s d1 + s d2
+            asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(vt[2][c]) : "v"(d1), "s"(sc), "v"(t2));     // V2 = s d2 - s d1
+            asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(vt[3][c]) : "v"(d1), "s"(sc), "v"(t3));     // V3 = s d1 - s d3
         }
-#define F23_V(T, C) vt[T][C]
-#endif
-        unsigned char* dst = sm + buf * BUF + sL;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             u32x4 hv, lv;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const float x0 = F23_V(t, 2 * c), x1 = F23_V(t, 2 * c + 1);
+                const float x0 = vt[t][2 * c], x1 = vt[t][2 * c + 1];
                 const unsigned h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
                 unsigned l;
                 asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=&v"(l) : "v"(h), "v"(x0));
@@ -390,12 +368,43 @@ modconv_f23_kernel(F23Params p) {
                 *reinterpret_cast<u32x4*>(dst + (t * 4 + 2) * PLANE) = lv;
             }
         }
+        } else {
+        // fp16 tensors: a request register holds two halfs (d0 | d1 << 16), (d2 | d3 << 16).  The mixed-precision FMA reads them where
+        // they lie (op_sel picks the half, op_sel_hi marks the operand as fp16), multiplies by the fp32 style scale, adds the fp32
+        // partner term and rounds ONCE to fp16 (round to nearest even, the mode register's default) into the low | high half of the
+        // packed result: six single-issue instructions per channel, no separate conversion or split.
+        unsigned hw[4][4];                                               // [transform point][channel pair]
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const unsigned sc = rsc[c];
+            const unsigned own = rb[c][0], right = rb[c][1];
+            float t2, t3;
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(t2) : "v"(right), "s"(sc));                       // s d2
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t3) : "v"(right), "s"(sc));         // s d3
+            unsigned& o0 = hw[0][c >> 1]; unsigned& o1 = hw[1][c >> 1]; unsigned& o2 = hw[2][c >> 1]; unsigned& o3 = hw[3][c >> 1];
+            if ((c & 1) == 0) {
+                asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[1,0,0]" : "=&v"(o0) : "v"(own), "s"(sc), "v"(t2));                   // V0 = s d0 - s d2
+                asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(o1) : "v"(own), "s"(sc), "v"(t2));     // V1 = s d1 + s d2
+                asm("v_fma_mixlo_f16 %0, -%1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(o2) : "v"(own), "s"(sc), "v"(t2));    // V2 = s d2 - s d1
+                asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(o3) : "v"(own), "s"(sc), "v"(t3));    // V3 = s d1 - s d3
+            } else {
+                asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel_hi:[1,0,0]" : "+v"(o0) : "v"(own), "s"(sc), "v"(t2));
+                asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(o1) : "v"(own), "s"(sc), "v"(t2));
+                asm("v_fma_mixhi_f16 %0, -%1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(o2) : "v"(own), "s"(sc), "v"(t2));
+                asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(o3) : "v"(own), "s"(sc), "v"(t3));
+            }
+        }
+        if (sOk) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) *reinterpret_cast<u32x4*>(dst + (t * 2) * PLANE) = (u32x4){hw[t][0], hw[t][1], hw[t][2], hw[t][3]};
+        }
+        }
     };
     struct BFrag { v8h h, l; };
     auto load_b = [&](BFrag& f, int buf, int q) {
         const unsigned char* src = sm + buf * BUF + bR + q * 256;
         f.h = *reinterpret_cast<const v8h*>(src);
-        f.l = *reinterpret_cast<const v8h*>(src + 2 * PLANE);
+        if constexpr (SPLIT) f.l = *reinterpret_cast<const v8h*>(src + 2 * PLANE);
     };
     // an M block of pure channel padding (O = 203: channels 224..255 of the fourth tile) stages and synchronises but issues no MFMAs
     const bool active = o0 + mb * 32 < p.O;                                  // wave-uniform
@@ -414,12 +423,12 @@ modconv_f23_kernel(F23Params p) {
         if constexpr ((Q) < TN + 2) { \
             if constexpr ((Q) + 1 < TN + 2) load_b(b1, buf, (Q) + 1); \
             __builtin_amdgcn_sched_barrier(0); \
-            f23_mfma_row<AB, TN, (Q)>(b0.h, b0.l); \
+            if constexpr (SPLIT) f23_mfma_row<AB, TN, (Q)>(b0.h, b0.l); else f23_mfma_row_f16<AB, TN, (Q)>(b0.h); \
             __builtin_amdgcn_sched_barrier(0); \
             if constexpr ((Q) + 1 < TN + 2) { \
                 if constexpr ((Q) + 2 < TN + 2) load_b(b0, buf, (Q) + 2); \
                 __builtin_amdgcn_sched_barrier(0); \
-                    f23_mfma_row<AB, TN, (Q) + 1>(b1.h, b1.l); \
+                if constexpr (SPLIT) f23_mfma_row<AB, TN, (Q) + 1>(b1.h, b1.l); else f23_mfma_row_f16<AB, TN, (Q) + 1>(b1.h); \
                 __builtin_amdgcn_sched_barrier(0); \
             } \
         }
@@ -471,7 +480,7 @@ modconv_f23_kernel(F23Params p) {
         // ONE MFMA site in the loop (the accumulators must not become a phi of two branches: hipcc then keeps two copies of them)
         if (late) {
             if (ch == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            F23_WAIT_B(6);
+            F23_WAIT_B_NA();
             F23_STAMP(h1);
             if (more1) stage(buf ^ 1);
             F23_STAMP(h2);
@@ -486,7 +495,7 @@ modconv_f23_kernel(F23Params p) {
         if (buf) mfma_chunk(std::integral_constant<int, 24>{}, 1); else mfma_chunk(std::integral_constant<int, 0>{}, 0);
         F23_STAMP(tC);
         if (!late) {
-            F23_WAIT_B(6);
+            F23_WAIT_B_NA();
             F23_STAMP(h1);
             if (more1) stage(buf ^ 1);
             F23_STAMP(h2);
@@ -509,16 +518,7 @@ modconv_f23_kernel(F23Params p) {
     // until they have landed: the wait names them.  (An operand-less s_waitcnt here let hipcc reuse them for the epilogue's addresses
     // before the wait, and the returning zeros overwrote those.)  The matrix instructions were issued from asm statements: the
     // compiler does not know their latency, so the accumulators are given the wait states an XDL result needs before they are read.
-#if F23_AGPR_PROBE == 1
-    fetch_a(nch + 2 + (nch & 1));                                            // probe: out-of-range request for a[0:23] IN FRONT of the closing wait
-#endif
     F23_WAIT_B(0);
-#if F23_AGPR_PROBE == 2
-    fetch_a(nch + 2 + (nch & 1));                                            // probe: the same request BEHIND the closing wait (round 3: NaN everywhere)
-#elif F23_AGPR_PROBE == 3
-    fetch_a(nch + 2 + (nch & 1));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 #ifdef SG3_F23_STAMPS
     if (p.stamps && lane == 0) {
@@ -542,11 +542,11 @@ modconv_f23_kernel(F23Params p) {
 #pragma unroll
         for (int j = 0; j < 4; j++) d[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, (oc + j) * 4, 0, 0));
     }
-    const unsigned planeB = (unsigned)(p.outH * p.outPitch) * 4u;
+    const unsigned planeB = (unsigned)(p.outH * p.outPitch) * (unsigned)EB;
     const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.out + (size_t)n * p.O * p.outH * p.outPitch), (short)0, (int)((unsigned)p.O * planeB), 0x00020000);
+        (void*)(static_cast<T*>(p.out) + (size_t)n * p.O * p.outH * p.outPitch), (short)0, (int)((unsigned)p.O * planeB), 0x00020000);
     const int gx = x0 + 2 * pq;
-    const unsigned colOff = gx < p.outW ? (unsigned)oc * planeB + (unsigned)gx * 4u : 0x80000000u;
+    const unsigned colOff = gx < p.outW ? (unsigned)oc * planeB + (unsigned)gx * (unsigned)EB : 0x80000000u;
     auto finish_row = [&](auto bc) {
         constexpr int b = decltype(bc)::value;
         float accv[16];
@@ -556,15 +556,20 @@ modconv_f23_kernel(F23Params p) {
         for (int r = 0; r < 16; r++) Xb[(wave * 16 + r) * 64 + lane] = accv[r];
         __syncthreads();
         const int gy = y0 + rg * TN + b;
-        const unsigned rowOff = gy < p.outH ? colOff + (unsigned)(gy * p.outPitch) * 4u : 0x80000000u;
+        const unsigned rowOff = gy < p.outH ? colOff + (unsigned)(gy * p.outPitch) * (unsigned)EB : 0x80000000u;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const float* src = Xb + ((mb * 4) * 16 + 4 * xi + j) * 64 + lane;
             const float m0 = src[0], m1 = src[16 * 64], m2 = src[2 * 16 * 64], m3 = src[3 * 16 * 64];
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             const float ya = (m0 + m1 + m2) * d[j], yb = (m1 - m2 - m3) * d[j];
-            const u32x2 v = {__builtin_bit_cast(unsigned, ya), __builtin_bit_cast(unsigned, yb)};
-            __builtin_amdgcn_raw_buffer_store_b64(v, orr, (int)(rowOff + (unsigned)j * planeB), 0, 0);
+            if constexpr (SPLIT) {
+                const u32x2 v = {__builtin_bit_cast(unsigned, ya), __builtin_bit_cast(unsigned, yb)};
+                __builtin_amdgcn_raw_buffer_store_b64(v, orr, (int)(rowOff + (unsigned)j * planeB), 0, 0);
+            } else {
+                const v2h h = round2(ya, yb);                              // fp16 output, round to nearest even (the reference's fp16 convolution result)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), orr, (int)(rowOff + (unsigned)j * planeB), 0, 0);
+            }
         }
     };
     finish_row(std::integral_constant<int, 0>{}); finish_row(std::integral_constant<int, 1>{});
@@ -587,13 +592,14 @@ modconv_f23_kernel(F23Params p) {
     }   // tiles of this workgroup
 }
 
-int64_t f23_packed_floats(int O, int I) {
-    return (int64_t)ceil_div(O, 64) * ceil_div(I, 16) * (2 * 4 * 6 * 1024 / 4);
+int64_t f23_packed_floats(int O, int I, bool split) {
+    return (int64_t)ceil_div(O, 64) * ceil_div(I, 16) * (2 * 4 * (split ? 6 : 3) * 1024 / 4);
 }
 
 bool f23_supported(int dtype, int I, int O, int H, int W, int k, int pad, int outRowStride) {
-    if (k != 3 || dtype != SG3_F32) return false;
-    if ((W & 1) || (pad & 1)) return false;                                    // 8-byte aligned column pairs
+    if (k != 3 || (dtype != SG3_F32 && dtype != SG3_F16)) return false;
+    const long long eb = dtype == SG3_F32 ? 4 : 2;
+    if ((W & 1) || (pad & 1)) return false;                                    // aligned column pairs (8 bytes | 4 bytes)
     const int outH = H + 2 * pad - 2, outW = W + 2 * pad - 2;
     if (outH <= 0 || outW <= 0) return false;
     const long long pitch = outRowStride > 0 ? outRowStride : outW;
@@ -601,18 +607,19 @@ bool f23_supported(int dtype, int I, int O, int H, int W, int k, int pad, int ou
     // every store offset a lane can form (padded channels included) stays below 2^31 -- also on the 128-byte aligned row pitch the
     // inference path may choose AFTER the weights were packed in this kernel's order (the plan-time query passes outRowStride = 0)
     const long long worst = std::max<long long>(pitch, (outW + 31) / 32 * 32);
-    if ((long long)(ceil_div(O, 64) * 64 + 32) * outH * worst * 4 >= 0x7fffffffLL) return false;
-    if ((long long)I * H * W * 4 >= 0x7fffffffLL) return false;
+    if ((long long)(ceil_div(O, 64) * 64 + 32) * outH * worst * eb >= 0x7fffffffLL) return false;
+    if ((long long)I * H * W * eb >= 0x7fffffffLL) return false;
     if ((long long)ceil_div(O, 64) * ceil_div(I, 16) * 49152 >= 0x7fffffffLL) return false;
     return true;
 }
 
-template <int TN>
+template <int TN, typename T>
 static int launch_f23(const sg3_modconv_params& q, hipStream_t st) {
-    constexpr size_t ldsBytes = (size_t)2 * 16 * (2 * TN + 2) * 256;
-    static_assert(ldsBytes >= 65536 && ldsBytes <= 160 * 1024, "LDS: double-buffered B image, at least the 64 KB exchange area");
+    constexpr size_t imageBytes = (size_t)2 * (sizeof(T) == 4 ? 16 : 8) * (2 * TN + 2) * 256;
+    constexpr size_t ldsBytes = imageBytes > 65536 ? imageBytes : 65536;       // double-buffered B image, at least the 64 KB exchange area
+    static_assert(ldsBytes <= 160 * 1024, "LDS");
     F23Params p;
-    p.x = (const float*)q.x; p.wp = q.wPacked; p.sIn = q.sIn; p.dcoef = q.dcoef; p.out = (float*)q.out;
+    p.x = q.x; p.wp = q.wPacked; p.sIn = q.sIn; p.dcoef = q.dcoef; p.out = q.out;
     p.N = q.N; p.I = q.I; p.O = q.O; p.H = q.H; p.W = q.W; p.pad = q.pad;
     p.outH = q.H + 2 * q.pad - 2; p.outW = q.W + 2 * q.pad - 2;
     p.nch = ceil_div(q.I, 16);
@@ -624,7 +631,7 @@ static int launch_f23(const sg3_modconv_params& q, hipStream_t st) {
 #ifdef SG3_F23_STAMPS
     p.stamps = g_f23_stamps;
 #endif
-    auto kern = modconv_f23_kernel<TN>;
+    auto kern = modconv_f23_kernel<TN, T>;
     // per device, once: the CU count (grid of persistent workgroups) and this instantiation's dynamic-LDS limit
     struct DevState { int cus; bool attr; };
     static DevState devs[64] = {};
@@ -668,10 +675,17 @@ int launch_conv_f23(const sg3_modconv_params& q, hipStream_t st) {
         if (cost < bestCost * 0.999) { bestCost = cost; best = tn; }
     }
     if (forced == 4 || forced == 5 || forced == 7) best = forced;
+    if (q.dtype == SG3_F16) {
+        switch (best) {
+            case 4: return launch_f23<4, _Float16>(q, st);
+            case 5: return launch_f23<5, _Float16>(q, st);
+            default: return launch_f23<7, _Float16>(q, st);
+        }
+    }
     switch (best) {
-        case 4: return launch_f23<4>(q, st);
-        case 5: return launch_f23<5>(q, st);
-        default: return launch_f23<7>(q, st);
+        case 4: return launch_f23<4, float>(q, st);
+        case 5: return launch_f23<5, float>(q, st);
+        default: return launch_f23<7, float>(q, st);
     }
 }
 

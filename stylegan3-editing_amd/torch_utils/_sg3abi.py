@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_PKG_ROOT, 'lib', 'libsg3hip.so')
 
 SG3_OK, SG3_NO_KERNEL, SG3_BAD_ARG, SG3_HIP_ERROR = 0, -1, -2, -3
 SG3_F32, SG3_F16, SG3_F64 = 0, 1, 2
-SG3_CONV_FP32, SG3_CONV_F16X3, SG3_CONV_F16, SG3_CONV_F16X3_F23 = 0, 1, 2, 3
+SG3_CONV_FP32, SG3_CONV_F16X3, SG3_CONV_F16, SG3_CONV_F16X3_F23, SG3_CONV_F16_F23 = 0, 1, 2, 3, 4
 _DTYPE = {torch.float32: SG3_F32, torch.float16: SG3_F16, torch.float64: SG3_F64}
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p

@@ -36,6 +36,9 @@ precision = 'f16x3'
 # two thirds of the matrix instructions).  'auto': layers whose channel counts fill its 64-channel x 16-channel tiles;
 # 'on': every call the kernel supports; 'off': never.  SG3_CONV_F23 in the environment sets the initial value.
 f23 = {'0': 'off', '1': 'on'}.get(os.environ.get('SG3_CONV_F23', ''), 'auto')
+# fp16 tensors (SG3_CONV_F16_F23): with a third of the matrix instructions per K step the transform-domain kernel's per-chunk
+# overhead weighs more, so it takes over from the direct fp16 kernel at larger I x O only (measured, see _f23_wanted)
+_F23_FP16_MIN_IO = 4000
 # `align_rows` requests are honoured unless SG3_CONV_DENSE_ROWS=1 (A/B timing of the padded row pitch)
 _ALIGN_ROWS = os.environ.get('SG3_CONV_DENSE_ROWS', '0') != '1'
 
@@ -71,7 +74,7 @@ def _effective_weights(w, s, demodulate, input_gain, n):
     return w
 
 
-def _f23_wanted(ci, co, h, wd, padding):
+def _f23_wanted(ci, co, h, wd, padding, fp16=False):
     """Heuristic of `f23 = 'auto'`: the transform-domain kernel works on 64 output channels x 16 input channels x 32 columns;
     thin layers (few K chunks per tile, HBM-bound) and narrow planes stay on the direct kernel."""
     if f23 == 'on':
@@ -81,6 +84,8 @@ def _f23_wanted(ci, co, h, wd, padding):
     # L9 695 -> 627; since then the thin layers gain too: L10 (128 -> 81: 8 chunks per tile) 1527 direct -> 1398, L11 (81 -> 51) 2453 ->
     # 2293; L12 (51 -> 32: 4 chunks, half an M tile) loses, 1014 -> 1456, and the 38-column planes of L0-L2 fill 59 % of two column tiles
     ow = wd + 2 * padding - 2
+    if fp16:
+        return ci * co >= _F23_FP16_MIN_IO and co >= 48 and ow >= 48
     return ci * co >= 4000 and co >= 48 and ow >= 48
 
 
@@ -143,9 +148,12 @@ def _plan(w, s, demodulate, padding, input_gain, x_bound, x_bound_dev, n, h, wd,
     # 1x1: ToRGB (O <= 4) is HBM-bound and has its own kernel; the GEMM kernel loads pixel pairs (even plane size)
     split = precision == 'f16x3' and (k == 3 or (padding == 0 and co > 4 and (h * wd) % 2 == 0)) and bounded
     prec = (abi.SG3_CONV_F16 if dtype == torch.float16 else abi.SG3_CONV_F16X3) if split else abi.SG3_CONV_FP32
-    if prec == abi.SG3_CONV_F16X3 and k == 3 and f23 != 'off' and _f23_wanted(ci, co, h, wd, int(padding)) \
+    if prec == abi.SG3_CONV_F16X3 and dtype == torch.float32 and k == 3 and f23 != 'off' and _f23_wanted(ci, co, h, wd, int(padding)) \
             and lib.sg3_modconv_f23_supported(abi.SG3_F32, ci, co, h, wd, k, int(padding), 0):
         prec = abi.SG3_CONV_F16X3_F23
+    elif prec == abi.SG3_CONV_F16 and dtype == torch.float16 and k == 3 and f23 != 'off' and _f23_wanted(ci, co, h, wd, int(padding), fp16=True) \
+            and lib.sg3_modconv_f23_supported(abi.SG3_F16, ci, co, h, wd, k, int(padding), 0):
+        prec = abi.SG3_CONV_F16_F23                         # the reference's use_fp16 layers: same transform domain, one product per K step
     pr = _Prepared()
     pr.prec = prec
     pr.key = (n, ci, co, k, h, wd, int(padding), dtype)

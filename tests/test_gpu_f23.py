@@ -193,3 +193,40 @@ def test_f23_data_gradient_at_layer_shapes_matches_fp64(ci, co, h):
     # and the forward of the same call, for completeness of the pair
     fref = O.modulated_conv2d(x.astype(np.float64), w64, s64, True, 2, gain)
     assert maxabs(y.detach().cpu().numpy(), fref) <= 5e-6 * max(1.0, float(np.abs(fref).max()))
+
+
+@pytest.mark.parametrize('n,ci,co,h,w,pad', [
+    (2, 64, 64, 30, 30, 2),
+    (1, 323, 203, 22, 26, 2),          # padded K chunk, an M block of pure padding
+    (2, 81, 51, 40, 70, 2),            # second M block partly inactive, ragged column tiles
+    (1, 512, 512, 20, 36, 2),          # 32 chunks
+    (3, 17, 130, 35, 34, 0),           # pad 0, two K chunks
+])
+@pytest.mark.parametrize('tn', [4, 5, 7])
+def test_f23_fp16_form_matches_the_direct_fp16_kernel_and_the_oracles(n, ci, co, h, w, pad, tn):
+    """SG3_CONV_F16_F23 (round 4): fp16 tensors -- the reference's `use_fp16` layers (networks_stylegan3.py:355-366, :61) -- in the
+    transform domain: transformed inputs / weights rounded to fp16 once, one product per K step, fp32 accumulation, fp16 output.
+    Yardsticks: the fp64 oracle (the exact result), the fp16-rounding oracle (`modulated_conv2d_fp16`: the reference's rounding points,
+    unpinned) and the direct fp16 kernel, which rounds x * s and w instead of their transforms: the transform-domain form may be a
+    small factor less accurate than the direct one (three rounded products are summed per output) but stays an fp16-grade result."""
+    from oracle import oracle as O
+    from torch_utils import _sg3abi as abi
+    x = np.clip(rand(171, n, ci, h, w) * 40, -256, 256).astype(np.float16)
+    wt = rand(172, co, ci, 3, 3); s = (rand(173, n, ci) + 1).astype(np.float32)
+    ref64 = O.modulated_conv2d(x.astype(np.float64), wt.astype(np.float64), s.astype(np.float64), True, pad, 0.8)
+    ref16 = O.modulated_conv2d_fp16(x, wt, s, True, pad, 0.8).astype(np.float64)
+    scale = max(1.0, float(np.abs(ref64).max()))
+    kw = dict(demodulate=True, padding=pad, input_gain=torch.tensor(0.8, device=DEV), x_bound=256.0)
+    with _f23('on', tn) as mc:
+        assert abi.load().sg3_modconv_f23_supported(abi.SG3_F16, ci, co, h, w, 3, pad, 0) == 1
+        y = mc.modulated_conv2d(T(x), T(wt), T(s), **kw)
+    with _f23('off') as mc:
+        yd = mc.modulated_conv2d(T(x), T(wt), T(s), **kw)
+    assert y.dtype == torch.float16 and tuple(y.shape) == ref64.shape
+    y64, yd64 = y.float().cpu().numpy().astype(np.float64), yd.float().cpu().numpy().astype(np.float64)
+    e23, ed, eo = maxabs(y64, ref64) / scale, maxabs(yd64, ref64) / scale, maxabs(ref16, ref64) / scale
+    m23, md = float(np.abs(y64 - ref64).mean()) / scale, float(np.abs(yd64 - ref64).mean()) / scale
+    print(f'vs fp64, relative to max |y|: transform-domain fp16 max {e23:.2e} mean {m23:.2e}; direct fp16 max {ed:.2e} mean {md:.2e}; fp16 oracle max {eo:.2e}')
+    assert bool(torch.isfinite(y).all())
+    assert e23 <= 4e-3 and m23 <= 4e-4, (e23, m23)
+    assert e23 <= 3.0 * max(ed, eo) + 2.5e-4 and m23 <= 3.0 * md + 1e-5, (e23, ed, eo, m23, md)
