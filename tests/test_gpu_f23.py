@@ -104,12 +104,13 @@ def test_f23_aligned_row_pitch_and_batch_independence(n, ci, co, h):
 
 
 def test_f23_unsupported_shapes_fall_back():
-    """Odd widths / odd padding / fp16 tensors are refused by the query and run on the direct kernel."""
+    """Odd widths / odd padding are refused by the query and run on the direct kernel."""
     from torch_utils import _sg3abi as abi
     lib = abi.load()
     assert lib.sg3_modconv_f23_supported(abi.SG3_F32, 64, 64, 30, 31, 3, 2, 0) == 0
     assert lib.sg3_modconv_f23_supported(abi.SG3_F32, 64, 64, 30, 30, 3, 1, 0) == 0
-    assert lib.sg3_modconv_f23_supported(abi.SG3_F16, 64, 64, 30, 30, 3, 2, 0) == 0
+    assert lib.sg3_modconv_f23_supported(abi.SG3_F16, 64, 64, 30, 30, 3, 2, 0) == 1       # fp16 tensors: the SG3_CONV_F16_F23 form (round 4)
+    assert lib.sg3_modconv_f23_supported(abi.SG3_F16, 64, 64, 30, 31, 3, 2, 0) == 0
     assert lib.sg3_modconv_f23_supported(abi.SG3_F32, 64, 64, 30, 30, 1, 0, 0) == 0
     assert lib.sg3_modconv_f23_supported(abi.SG3_F32, 64, 64, 30, 30, 3, 2, 0) == 1
     from oracle import oracle as O

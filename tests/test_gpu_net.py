@@ -142,8 +142,9 @@ def test_mixed_precision_default_path():
     ref16 = O.synthesis(sd, sched, ws=ws.cpu().numpy(), mixed_fp16=True)
     d16 = np.abs(a.cpu().numpy() - ref16)
     print(f'mixed vs own fp32: max {float(d.max()):.3e} mean {float(d.mean()):.3e};  mixed vs fp16 oracle: max {d16.max():.3e} mean {d16.mean():.3e}')
-    assert d16.max() <= 1e-2 and d16.mean() <= 1e-3, (d16.max(), d16.mean())
-    assert float(d.max()) <= 5e-2 and float(d.mean()) <= 3e-3
+    # the same bounds as the T-256 test (the 1e-2 / 1e-3 of round 3 were 20 x what was measured)
+    assert d16.max() <= 2e-3 and d16.mean() <= 3e-4, (d16.max(), d16.mean())
+    assert float(d.max()) <= 5e-3 and float(d.mean()) <= 5e-4
 
 
 def test_graphed_synthesis_replay_equals_eager():
