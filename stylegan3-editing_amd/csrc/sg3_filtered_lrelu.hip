@@ -595,7 +595,23 @@ struct Stream {
                         for (int q = 1; q < Cfg::FD / 2; q++) { y0 = fma2(pr[q], st.tdP[q], y0); y1 = fma2(pr[q + 1], st.tdP[q], y1); }
                         const float f0 = (y0.x + y0.y) * gainOut, f1 = (y1.x + y1.y) * gainOut;
                         if (SIGNS == 2) st.osum += (2 * lane < oxN ? f0 : 0.f) + (2 * lane + 1 < oxN ? f1 : 0.f);
+#ifdef SG3_FUSION_BOUND
+                        // diagnostic builds of tools/flrelu_fusion_bound.hip ONLY (never in the product library): what a fusion of this
+                        // layer with the ToRGB convolution behind it could cost at least.  1: the activation plane is not stored at all
+                        // (the outputs are only kept alive); 2: instead, the wave's share of the three RGB partial sums -- three packed
+                        // multiplies with wave-uniform weights and three 8-byte LDS writes per lane and row; the exchange between the
+                        // waves of a pixel (LDS reads, adds, barrier) and the store of the partial image are NOT included.
+                        if (SG3_FUSION_BOUND >= 2) {
+                            lds_v2f* rgbx = reinterpret_cast<lds_v2f*>(sOut + Cfg::SOUT);
+#pragma unroll
+                            for (int k = 0; k < 3; k++) rgbx[k * 64 + lane] = (v2f){f0, f1} * splat(p.slope * (float)(k + 1));
+                        } else {
+                            asm volatile("" :: "v"(f0), "v"(f1));
+                        }
+                        if (false) {
+#else
                         if (pairStore) {
+#endif
                             bufio<T>::st2(rs, G > 1 ? st.ooff[0] : 2 * lane * (int)sizeof(T), f0, f1);
                         } else {
                             bufio<T>::st1(rs, G > 1 ? st.ooff[0] : 2 * lane * (int)sizeof(T), f0);
@@ -627,7 +643,11 @@ struct Stream {
         static_assert(!RDOWN || (D == 2 && SIGNS != 2), "radial down filter: forward passes (plain or sign-writing), down 2");
         static_assert(!UP2D || (U == 2 && SIGNS == 2), "2-D up filter: the adjoint pass, up 2");
         static_assert(G == 1 || (G == 2 && SIGNS == 0 && D == 2), "packed mode: plain forward, down 2, two planes");
+#ifdef SG3_FUSION_BOUND
+        __shared__ __attribute__((aligned(16))) float lds[Cfg::SIN + Cfg::SOUT + 3 * 128];      // + the diagnostic RGB rows
+#else
         __shared__ __attribute__((aligned(16))) float lds[Cfg::SIN + Cfg::SOUT];
+#endif
         lds_f* sIn = (lds_f*)lds;
         lds_f* sOut = (lds_f*)lds + Cfg::SIN;                               // row exchanged for the horizontal down pass
         const int lane = threadIdx.x;

@@ -384,14 +384,21 @@ class SynthesisLayer(torch.nn.Module):
         return (self.is_torgb and self.up_factor == 1 and self.down_factor == 1 and self.up_filter is None and self.down_filter is None
                 and not any(self.padding) and _modconv.torgb_epilogue_ok(self.weight, self.conv_kernel - 1, dtype))
 
-    def forward(self, x, w, styles=None, noise_mode='random', force_fp32=False, update_emas=False, prepared=None, out_scale=1.0):
+    def forward(self, x, w, styles=None, noise_mode='random', force_fp32=False, update_emas=False, prepared=None, out_scale=1.0, input_gain=None):
         assert noise_mode in ['random', 'const', 'none']  # kept for API compatibility; SG3 has no noise inputs
         in_w, in_h = (int(v) for v in self.in_size)
         out_w, out_h = (int(v) for v in self.out_size)
         misc.assert_shape(x, [None, self.in_channels, in_h, in_w])
         if update_emas:
             self._track_magnitude(x)
-        input_gain = self.magnitude_ema.rsqrt() if prepared is None else None      # a prepared convolution carries it
+        # a prepared convolution carries the gain; with gradients recorded the backward's closed forms need its value as well
+        # (`input_gain`: the network's cached rsqrt(magnitude_ema) of this layer, handed in with the batched preparation)
+        if prepared is None:
+            input_gain = self.magnitude_ema.rsqrt()
+        elif not torch.is_grad_enabled():
+            input_gain = None
+        elif input_gain is None:
+            input_gain = self.magnitude_ema.rsqrt()
 
         if styles is None:
             misc.assert_shape(w, [x.shape[0], self.w_dim])
@@ -399,7 +406,7 @@ class SynthesisLayer(torch.nn.Module):
 
         dtype = self.compute_dtype(force_fp32, x.device.type)
         epilogue = None
-        if prepared is not None and self.fuses_output(dtype):
+        if prepared is not None and not torch.is_grad_enabled() and self.fuses_output(dtype):
             epilogue = (self.bias, self.conv_clamp, float(out_scale))       # clamp(conv + bias) [* out_scale] inside the convolution
         elif out_scale != 1.0:
             raise RuntimeError('SynthesisLayer: out_scale rides in the fused ToRGB output stage only')
@@ -520,7 +527,10 @@ class SynthesisNetwork(torch.nn.Module):
         given = ws if all_s is None else all_s['input']
         # Inference on the GPU: every layer's styles are known before the first convolution, so the weight / style preparation
         # of all convolutions is issued as one batch (two launches instead of thirty small, latency-bound ones)
-        batched = (self.batch_prep and given.is_cuda and not torch.is_grad_enabled() and not layer_kwargs.get('update_emas', False)
+        # With gradients recorded (pivotal tuning: thirty prep launches per forward otherwise) the preparation is batched the same way --
+        # the styles then come from the layers' own differentiable affine modules, and each layer is handed its input gain for the backward
+        grad = torch.is_grad_enabled()
+        batched = (self.batch_prep and given.is_cuda and not layer_kwargs.get('update_emas', False)
                    and all(k in ('noise_mode', 'force_fp32', 'update_emas') for k in layer_kwargs))
         # modules whose own forward the merged kernels bypass keep it when somebody hooked them (hooks must keep firing)
         watched = bool(torch.nn.modules.module._global_forward_hooks) or bool(torch.nn.modules.module._global_forward_pre_hooks) or any(
@@ -530,7 +540,7 @@ class SynthesisNetwork(torch.nn.Module):
             misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
             per_layer = ws.to(torch.float32).unbind(dim=1)
             styles = None
-            if not (batched and self.input.fast_path_ok() and not watched):
+            if not (batched and self.input.fast_path_ok() and not watched and not grad):
                 t_in = self.input.transform_params(per_layer[0])
         else:
             t_in = all_s['input']
@@ -539,9 +549,9 @@ class SynthesisNetwork(torch.nn.Module):
         x = None
         if batched:
             n = int(given.shape[0])
-            fast_input = self.input.fast_path_ok() and not watched
+            fast_input = self.input.fast_path_ok() and not watched and not grad
             normalise = False
-            if styles is None and watched:
+            if styles is None and (watched or grad):
                 styles = [layer.styles_from_w(w) for layer, w in zip(layers, per_layer[1:])]
             if styles is None:
                 # every affine layer (the input's and the 15 layers') in one launch instead of ~45 (affine_batch.py)
@@ -569,9 +579,11 @@ class SynthesisNetwork(torch.nn.Module):
                 # the network's output scale (reference :488-489) rides in the last layer's fused output stage
                 # (not when somebody watches the layer's own output through a forward hook)
                 hooked = bool(layer._forward_hooks) or bool(torch.nn.modules.module._global_forward_hooks)
-                last = (j + 1 == len(layers) and prepared[j] is not None and self.output_scale != 1 and not hooked
+                last = (j + 1 == len(layers) and prepared[j] is not None and self.output_scale != 1 and not hooked and not grad
                         and layer.fuses_output(layer.compute_dtype(bool(layer_kwargs.get('force_fp32', False)), 'cuda')))
-                x = layer(x, None, styles=styles[j], prepared=prepared[j], **(dict(layer_kwargs, out_scale=self.output_scale) if last else layer_kwargs))
+                extra = dict(input_gain=gains[j:j + 1].reshape([])) if (grad and prepared[j] is not None) else {}
+                x = layer(x, None, styles=styles[j], prepared=prepared[j], **extra,
+                          **(dict(layer_kwargs, out_scale=self.output_scale) if last else layer_kwargs))
                 scaled = last
             else:
                 x = layer(x, per_layer[j + 1], **layer_kwargs)
