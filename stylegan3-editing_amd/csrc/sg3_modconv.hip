@@ -337,7 +337,9 @@ modconv_f16x3_kernel(ConvParams p) {
                 v2h h[4], l[4];
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    const float v0 = rb[q][hf][2 * c] * sc[hf][2 * c], v1 = rb[q][hf][2 * c + 1] * sc[hf][2 * c + 1];
+                    // fp16 form: the two products would be SLP-packed into v_pk_mul_f32 (the split form's bit masks keep them apart)
+                    const float v0 = SPLIT ? rb[q][hf][2 * c] * sc[hf][2 * c] : mul_single(rb[q][hf][2 * c], sc[hf][2 * c]);
+                    const float v1 = SPLIT ? rb[q][hf][2 * c + 1] * sc[hf][2 * c + 1] : mul_single(rb[q][hf][2 * c + 1], sc[hf][2 * c + 1]);
                     if (SPLIT) split2(v0, v1, h[c], l[c]);
                     else h[c] = round2(v0, v1);
                 }
@@ -616,7 +618,9 @@ modconv_flat_kernel(ConvParams p) {
                 v2h h[4], l[4];
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    const float v0 = rb[q][hf][2 * c] * sc[hf][2 * c], v1 = rb[q][hf][2 * c + 1] * sc[hf][2 * c + 1];
+                    // fp16 form: the two products would be SLP-packed into v_pk_mul_f32 (the split form's bit masks keep them apart)
+                    const float v0 = SPLIT ? rb[q][hf][2 * c] * sc[hf][2 * c] : mul_single(rb[q][hf][2 * c], sc[hf][2 * c]);
+                    const float v1 = SPLIT ? rb[q][hf][2 * c + 1] * sc[hf][2 * c + 1] : mul_single(rb[q][hf][2 * c + 1], sc[hf][2 * c + 1]);
                     if (SPLIT) split2(v0, v1, h[c], l[c]);
                     else h[c] = round2(v0, v1);
                 }
@@ -795,7 +799,7 @@ modconv1_f16x3_kernel(ConvParams p) {
             const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rsc), c));
             float v0, v1;
             bufld<T>::unpack2(rb[c], v0, v1);
-            rv[c][0] = v0 * sc; rv[c][1] = v1 * sc;
+            rv[c][0] = SPLIT ? v0 * sc : mul_single(v0, sc); rv[c][1] = SPLIT ? v1 * sc : mul_single(v1, sc);      // fp16 form: no v_pk_mul_f32 (see mul_single)
         }
 #pragma unroll
         for (int q = 0; q < A_PER; q++)
