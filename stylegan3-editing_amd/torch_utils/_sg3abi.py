@@ -10,7 +10,8 @@ import os
 import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, 'lib', 'libsg3hip.so')
+# SG3_LIB: another build of the same library (same-box A/B timing of kernel variants from tools/); the product loads its own lib/ copy
+LIB_PATH = os.environ.get('SG3_LIB') or os.path.join(_PKG_ROOT, 'lib', 'libsg3hip.so')
 
 SG3_OK, SG3_NO_KERNEL, SG3_BAD_ARG, SG3_HIP_ERROR = 0, -1, -2, -3
 SG3_F32, SG3_F16, SG3_F64 = 0, 1, 2

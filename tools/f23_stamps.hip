@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
     size_t maxIn = 0, maxOut = 0, maxW = 0;
     for (const Layer& L : layers) {
         maxIn = std::max(maxIn, (size_t)N * L.I * L.H * L.H); maxOut = std::max(maxOut, (size_t)N * L.O * (L.H + 2) * (L.H + 2));
-        maxW = std::max(maxW, (size_t)sg3::f23_packed_floats(L.O, L.I));
+        maxW = std::max(maxW, (size_t)sg3::f23_packed_floats(L.O, L.I, true));
     }
     float *x, *out, *sIn, *dcoef, *wp; unsigned long long* stamps;
     const size_t stampWgs = 1u << 16;                 // 64 u64 per workgroup in each half of the buffer
