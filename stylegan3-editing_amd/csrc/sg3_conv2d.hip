@@ -448,6 +448,18 @@ conv2d_pack_f16x3_kernel(const float* w, const float* outScale, float* wp, int O
     }
 }
 
+// CUs of the current device, read once per device
+static int device_cu_count() {
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
+}
+
 template <int KS, int STRIDE, int WM, int WN, int TM, int TN>
 static int launch_plain_f16x3(const sg3_conv2d_params& q, hipStream_t st) {
     constexpr int BM = WM * TM * 32, ROWS = WN * TN;
@@ -473,8 +485,14 @@ static int dispatch_plain_f16x3(const sg3_conv2d_params& q, hipStream_t st) {
     if (q.k == 1)                                                                    // the projection shortcuts: same kernel, one tap
         return q.stride == 2 ? launch_plain_f16x3<1, 2, 1, 4, 2, 1>(q, st) : launch_plain_f16x3<1, 1, 1, 4, 2, 1>(q, st);
     if (q.stride == 2) return launch_plain_f16x3<3, 2, 1, 4, 2, 1>(q, st);        // 64 x (4 rows x 32), 9 x 65 patch
-    const int outH = q.H + 2 * q.pad - 2;
+    const int outH = q.H + 2 * q.pad - 2, outW = q.W + 2 * q.pad - 2;
     if (outH <= 16) return launch_plain_f16x3<3, 1, 1, 4, 2, 1>(q, st);           // 64 x (4 rows x 32): the 16x16 maps
+    // The 8-row tile (230 registers: two workgroups per CU) needs a grid that offers every CU its two workgroups; the 32 x 32 maps
+    // of a 16-frame batch (14 units of the IR-SE50 trunk, 28 launches) give 256 eight-row tiles = ONE four-wave workgroup per CU
+    // (counters, round 4: 0.85 waves per SIMD, matrix pipes 0.32 busy at 2.45 GHz -- latency, not power).  Such grids take the
+    // 4-row tile instead (153 registers, three workgroups per CU): twice the workgroups, each with half the rows.
+    const long long tiles8 = (long long)q.N * ceil_div(q.O, 64) * ceil_div(outH, 8) * ceil_div(outW, 32);
+    if (tiles8 < 2 * (long long)device_cu_count()) return launch_plain_f16x3<3, 1, 1, 4, 2, 1>(q, st);
     return launch_plain_f16x3<3, 1, 1, 4, 2, 2>(q, st);                           // 64 x (8 rows x 32)
 }
 
