@@ -11,7 +11,9 @@
 //     M_xi[o, y, p] = sum_{ky, i} U_xi[o,i,ky] * V_xi[i, y+ky, p]                (the matrix-core work: K = 3 I per xi)
 //     out(2p) = M0 + M1 + M2      out(2p+1) = M1 - M2 - M3                       (output transform, once per tile)
 // Each V and U value is split into fp16 hi + lo and every 16-channel K step runs three v_mfma_f32_32x32x16_f16
-// (Uh Vh + Uh Vl + Ul Vh), exactly as the direct kernel does with x and w.
+// (Uh Vh + Uh Vl + Ul Vh), exactly as the direct kernel does with x and w (T = float, SG3_CONV_F16X3_F23).  For fp16 tensors -- the
+// reference's `use_fp16` layers, networks_stylegan3.py:355-366 -- the same kernel runs with V and U rounded to fp16 once and ONE
+// product per K step (T = _Float16, SG3_CONV_F16_F23).
 //
 // Work split (one 512-thread workgroup per CU, 8 waves): wave = (xi, M block): it owns ONE transform point for 32 output
 // channels and the whole pixel tile, so a wave touches a quarter of the weight image and keeps ONE accumulator set
@@ -22,8 +24,9 @@
 // A fragments (U) never pass through LDS: the pack kernel writes them in MFMA lane order per (M tile, chunk, M block, xi), and
 // a wave loads its six 1 KB fragments of the next chunk straight into registers (a 6 KB contiguous run, L2 resident).
 // B image (V): [xi][hi|lo][channel half][patch row][pair][8 channels] halfs, double buffered; staged by all waves: a thread
-// owns (patch row, pair, channel half), loads 8 channels x 4 columns (two 8-byte loads per channel), transforms, splits and
-// writes eight 16-byte vectors.  One barrier per 16-channel chunk.  Waves 4-7 (the second wave of every SIMD) run the
+// owns (patch row, pair, channel half), loads 8 channels x 4 columns (two 8-byte loads per channel), transforms with SINGLE-ISSUE
+// fp32 instructions (packed fp32 is the one vector class that stalls the SIMD's matrix pipe, profiles/r04_mfma_valu_coissue.txt),
+// splits and writes eight 16-byte vectors; the style scales come through the scalar cache.  One barrier per 16-channel chunk.  Waves 4-7 (the second wave of every SIMD) run the
 // chunk body in the order stage-then-MFMA, waves 0-3 MFMA-then-stage, so that one wave's staging arithmetic sits beside the
 // other's matrix instructions instead of both waves alternating in lockstep.
 #include "sg3_common.h"
