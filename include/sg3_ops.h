@@ -491,6 +491,12 @@ typedef struct sg3_modgrad_params {
 
 SG3_API int sg3_modulation_backward(const sg3_modgrad_params* p, void* stream);
 
+/* The weights of the DATA-GRADIENT convolution of modulated_conv2d in one launch: the reference's backward runs the grouped
+ * convolution's adjoint (autograd of networks_stylegan3.py:59-62), i.e. a convolution with the pre-normalised (:41-42, when
+ * `normalise`), transposed and flipped weights:  wt[i][o][k-1-ky][k-1-kx] = w[o][i][ky][kx] * rsqrt(mean_{i,ky,kx} w[o]^2).
+ * w [O,I,k,k] and wt [I,O,k,k] dense fp32.  Replaces six elementwise / reduction launches per layer and PTI step. */
+SG3_API int sg3_modconv_transpose_weights(const float* w, float* wt, int O, int I, int k, int normalise, void* stream);
+
 /* ------------------------------------------------------------------------
  * se_residual -- the tail of an IR-SE residual unit (models/setgan/encoder/encoders/helpers.py:57-73 SEModule and
  *   :117-120 bottleneck_IR_SE.forward):  out = shortcut + res * sigmoid(fc2 @ relu(fc1 @ mean_hw(res))).

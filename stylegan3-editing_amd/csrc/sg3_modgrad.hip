@@ -140,7 +140,33 @@ modgrad_dsfinal_kernel(sg3_modgrad_params p) {
     for (int j = threadIdx.x; j < NI; j += 256) p.dS[j] = b * p.dSn[j] - c * p.s[j];
 }
 
+// wt[i][o][T-1-t] = w[o][i][t] * a[o], a = rsqrt(mean w[o]^2) or 1: one workgroup per output channel (sg3_modconv_transpose_weights)
+__global__ void __launch_bounds__(256)
+modconv_transpose_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int O, int I, int T, int normalise) {
+    __shared__ float red[4];
+    const int o = blockIdx.x, IT = I * T;
+    const float* wo = w + (size_t)o * IT;
+    float a = 1.f;
+    if (normalise) {
+        float q = 0.f;
+        for (int j = threadIdx.x; j < IT; j += 256) { const float v = wo[j]; q += v * v; }
+        a = rsqrtf(block_sum(q, red) / (float)IT);
+    }
+    for (int j = threadIdx.x; j < IT; j += 256) {
+        const int i = j / T, t = j - i * T;
+        wt[((size_t)i * O + o) * T + (T - 1 - t)] = wo[j] * a;
+    }
+}
+
 } // namespace sg3
+
+extern "C" int sg3_modconv_transpose_weights(const float* w, float* wt, int O, int I, int k, int normalise, void* stream) {
+    using namespace sg3;
+    SG3_REQUIRE(w && wt && O > 0 && I > 0 && (k == 1 || k == 3), "modconv_transpose_weights: bad arguments");
+    hipLaunchKernelGGL(modconv_transpose_weights_kernel, dim3(O), dim3(256), 0, (hipStream_t)stream, w, wt, O, I, k * k, normalise ? 1 : 0);
+    SG3_LAUNCH_CHECK("modconv_transpose_weights_kernel");
+    return SG3_OK;
+}
 
 extern "C" int sg3_modulation_backward(const sg3_modgrad_params* p, void* stream) {
     using namespace sg3;

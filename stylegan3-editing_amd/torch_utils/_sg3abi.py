@@ -130,6 +130,7 @@ EXPORTS = [
     ('sg3_se_residual', ctypes.c_int, [ctypes.POINTER(SeParams), c_vp]),
     ('sg3_unfold3x3s2', ctypes.c_int, [ctypes.POINTER(UnfoldParams), c_vp]),
     ('sg3_modulation_backward', ctypes.c_int, [ctypes.POINTER(ModgradParams), c_vp]),
+    ('sg3_modconv_transpose_weights', ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp]),
     ('sg3_modulated_conv2d_prep', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), c_vp]),
     ('sg3_modulated_conv2d_prep_batch', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), ctypes.c_int, c_vp]),
     ('sg3_conv2d', ctypes.c_int, [ctypes.POINTER(Conv2dParams), c_vp]),

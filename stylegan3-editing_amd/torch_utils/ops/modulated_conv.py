@@ -254,14 +254,24 @@ def _data_gradient(dy, w, s_in, dcoef, demodulate, padding, dy_amax=None):
     scale vectors exchanged.  The bound the split-precision path needs is max |dy|, taken on the device."""
     n, co = int(dy.shape[0]), int(w.shape[0])
     k = int(w.shape[2])
-    wn = w.detach().to(torch.float32)
-    if demodulate:
-        wn = wn * wn.square().mean([1, 2, 3], keepdim=True).rsqrt()
-    wt = wn.flip([2, 3]).transpose(0, 1).contiguous()                         # [I,O,k,k]
+    wt = _transposed_weights(w, demodulate)                                   # [I,O,k,k]: normalised, transposed, flipped
     mod = dcoef if dcoef is not None else torch.ones([n, co], dtype=torch.float32, device=dy.device)
     bound = dy_amax if dy_amax is not None else _amax(dy)
     dx, _, _ = _launch(dy, wt, mod, False, k - 1 - padding, None, x_bound_dev=bound, out_scale=s_in)
     return dx
+
+
+def _transposed_weights(w, normalise):
+    """wt[i,o,k-1-ky,k-1-kx] = w[o,i,ky,kx] * rsqrt(mean w[o]^2) (the pre-normalisation of networks_stylegan3.py:41-42 when
+    `normalise`): the weights of the data-gradient convolution, one launch (sg3_modconv_transpose_weights) instead of the six of
+    `wn = w * w.square().mean([1,2,3], keepdim=True).rsqrt(); wn.flip([2,3]).transpose(0,1).contiguous()`."""
+    co, ci, k, _ = (int(v) for v in w.shape)
+    w32 = w.detach().to(torch.float32).contiguous()
+    wt = torch.empty([ci, co, k, k], dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        abi.check(abi.load().sg3_modconv_transpose_weights(abi.ptr(w32), abi.ptr(wt), co, ci, k, int(bool(normalise)), abi.stream_ptr(w.device)),
+                  'sg3_modconv_transpose_weights')
+    return wt
 
 
 def _amax(t):

@@ -815,3 +815,16 @@ def test_modulation_backward_kernels_match_autograd(n, co, ci, k, demod, gain):
     assert got_w.shape == ref_w.shape and got_s.shape == ref_s.shape
     assert float((got_w - ref_w).abs().max()) <= 2e-5 * max(1e-3, float(ref_w.abs().max()))
     assert float((got_s - ref_s).abs().max()) <= 2e-5 * max(1e-3, float(ref_s.abs().max()))
+
+
+@pytest.mark.parametrize('co,ci,k,norm', [(51, 81, 3, True), (512, 512, 3, True), (3, 32, 1, False), (7, 5, 3, False)])
+def test_transposed_weights_kernel_matches_the_torch_ops(co, ci, k, norm):
+    """sg3_modconv_transpose_weights: the data-gradient convolution's weights -- pre-normalised (networks_stylegan3.py:41-42), transposed,
+    flipped -- in one launch, against the six torch ops it replaces (round 4: PTI step housekeeping)."""
+    from torch_utils.ops import modulated_conv as mc
+    w = T(rand(301, co, ci, k, k) * 1.7)
+    ref = w * w.square().mean([1, 2, 3], keepdim=True).rsqrt() if norm else w
+    ref = ref.flip([2, 3]).transpose(0, 1).contiguous()
+    got = mc._transposed_weights(w, norm)
+    assert tuple(got.shape) == (ci, co, k, k)
+    assert maxabs(got.cpu().numpy(), ref.cpu().numpy()) <= 2e-6 * float(ref.abs().max())
