@@ -535,6 +535,30 @@ typedef struct sg3_unfold_params {
 
 SG3_API int sg3_unfold3x3s2(const sg3_unfold_params* p, void* stream);
 
+/* ----------------------------------------------------------------------
+ * Batched small-M GEMMs of the GradualStyleBlock heads (reference models/setgan/encoder/encoders/map2style.py:8-25: the 3x3
+ * stride-2 convolutions of levels 2.. as GEMMs over unfolded patches, and the closing EqualLinear, models/stylegan2/model.py
+ * EqualLinear.forward; restyle_psp_encoders.py:26-50 runs n_styles heads):
+ *     c[g][m][n] = sum_k lrelu(a[g][m][k], slope) * w[g][k][n] + bias[g][n]
+ *   float32 in and out, split-precision fp16 x 3 arithmetic on the matrix cores (fp32-equivalent), weight-bandwidth bound.
+ *   sg3_head_gemm_pack writes w ([G][K][N] float32, K % 16 == 0, N % 32 == 0) as matrix-instruction fragments into `packed`
+ *   (sg3_head_gemm_packed_halfs(G,K,N) fp16 elements, -1 for unsupported shapes); *rangeFlag is OR-ed with 1 when a weight
+ *   (pack) or an activation (gemm) lies outside the fp16 range: the caller then uses its fp32 path.  bias may be NULL.
+ * ---------------------------------------------------------------------- */
+typedef struct sg3_head_gemm_params {
+    const float*   a;              /* [G][M][K] dense */
+    const void*    wPacked;        /* from sg3_head_gemm_pack */
+    const float*   bias;           /* [G][N] or NULL */
+    float*         c;              /* [G][M][N] dense */
+    int32_t*       rangeFlag;
+    int32_t        G, M, K, N;
+    float          slope;          /* LeakyReLU applied to a on the way in; 1 = none */
+} sg3_head_gemm_params;
+
+SG3_API long long sg3_head_gemm_packed_halfs(int32_t G, int32_t K, int32_t N);
+SG3_API int sg3_head_gemm_pack(const float* w, void* packed, int32_t G, int32_t K, int32_t N, int32_t* rangeFlag, void* stream);
+SG3_API int sg3_head_gemm(const sg3_head_gemm_params* p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,13 @@ from models.setgan.encoder.encoders.helpers import bottleneck_IR, bottleneck_IR_
 from models.setgan.encoder.encoders.map2style import GradualStyleBlock
 
 
+# Rows (images x pixels) up to which a head level / the EqualLinear runs on sg3_head_gemm instead of torch.baddbmm (rocBLAS fp32).
+# Measured at 16 heads, N = 512 (profiles/r04_head_gemm.txt): K = 4608 -- 27.3 vs 28.0 us at 8 rows (both at the weight-read
+# rate, 5.5 TB/s), rocBLAS ahead from 32 rows on (its LDS-tiled A operand; ours re-reads A from L2 per column block);
+# K = 512 -- 11.4 vs 21.7 us up to 64 rows, and the LeakyReLU in front of it rides along.
+_HEAD_GEMM_MAX_ROWS = (16, 64)
+
+
 class _StyleHeadEncoder(Module):
     """What the two backbones share: `n_styles` GradualStyleBlock heads on the trunk's [N,512,16,16] map, the packed-weight
     cache of the fused GPU path, and the dispatch between that path and the plain PyTorch definition.  Subclasses provide the
@@ -87,6 +94,11 @@ class _StyleHeadEncoder(Module):
         pk['tail_b'] = [torch.stack([s.convs[2 * (l + 1)].bias for s in self.styles]).unsqueeze(1) for l in range(n_levels)]
         pk['lin_w'] = torch.stack([(s.linear.weight * s.linear.scale).t() for s in self.styles]).contiguous()   # [heads, in, out]
         pk['lin_b'] = torch.stack([s.linear.bias * s.linear.lr_mul for s in self.styles]).unsqueeze(1)
+        # The same operands as matrix-instruction fragments for sg3_head_gemm, which takes the GEMMs with few rows (see
+        # _HEAD_GEMM_MAX_ROWS); the fp32 tensors above stay for the larger ones and for the 'fp32' repeat of a flagged forward
+        from torch_utils.ops.head_gemm import PackedHeadWeights
+        pk['tail_g'] = [PackedHeadWeights(w, b) if PackedHeadWeights.supports(w) else None for w, b in zip(pk['tail_w'], pk['tail_b'])]
+        pk['lin_g'] = PackedHeadWeights(pk['lin_w'], pk['lin_b']) if PackedHeadWeights.supports(pk['lin_w']) else None
         self._packed = pk
 
     def _forward_hip(self, x):
@@ -111,6 +123,7 @@ class _StyleHeadEncoder(Module):
             self._pack()
             self._packed_key = key
         pk = self._packed
+        from torch_utils.ops import plain_conv
         from torch_utils.ops.unfold_ops import unfold3x3s2
         x = self._trunk_hip(pk, x.float())
         n, ci, sh, sw = (int(v) for v in x.shape)
@@ -131,16 +144,23 @@ class _StyleHeadEncoder(Module):
         src = h[0].view(heads, c, oh, n, period // 2)[..., :ow].permute(0, 3, 1, 2, 4)                # [heads, N, C, oh, ow] view
         slope = 1.0                                                                                   # level 1 leaves the kernel activated
         hh = None
-        for w, b in zip(pk['tail_w'], pk['tail_b']):
+        split = plain_conv.precision != 'fp32'
+        for w, b, wg in zip(pk['tail_w'], pk['tail_b'], pk['tail_g']):
             cols = unfold3x3s2(src, slope)                                                         # [heads, N*oh'*ow', 9*C]
             oh, ow = (oh + 1) // 2, (ow + 1) // 2
-            hh = torch.baddbmm(b, cols, w)                                                         # [heads, N*oh*ow, C], before its LeakyReLU
+            if split and wg is not None and wg.usable and n * oh * ow <= _HEAD_GEMM_MAX_ROWS[0]:
+                hh = wg.run(cols)
+            else:
+                hh = torch.baddbmm(b, cols, w)                                                     # [heads, N*oh*ow, C], before its LeakyReLU
             src = hh.view(heads, n, oh, ow, c).permute(0, 1, 4, 2, 3)
             slope = pk['slope']
         if oh * ow != 1 or hh is None:
             raise RuntimeError(f'style heads: a {sh}x{sw} feature map does not reduce to 1x1 in {len(pk["tail_w"]) + 1} halvings')
-        last = torch.nn.functional.leaky_relu(hh.view(heads, n, c), pk['slope'])
-        codes = torch.baddbmm(pk['lin_b'], last, pk['lin_w'])                                     # EqualLinear of every head
+        if split and pk['lin_g'] is not None and pk['lin_g'].usable and n <= _HEAD_GEMM_MAX_ROWS[1]:
+            codes = pk['lin_g'].run(hh.view(heads, n, c), pk['slope'])                            # LeakyReLU + EqualLinear of every head
+        else:
+            last = torch.nn.functional.leaky_relu(hh.view(heads, n, c), pk['slope'])
+            codes = torch.baddbmm(pk['lin_b'], last, pk['lin_w'])
         return self._combine(list(codes.unbind(0)))
 
     def forward(self, x):

@@ -82,6 +82,11 @@ class UnfoldParams(ctypes.Structure):
                 ('slope', c_f32)]
 
 
+class HeadGemmParams(ctypes.Structure):
+    _fields_ = [('a', c_vp), ('wPacked', c_vp), ('bias', c_vp), ('c', c_vp), ('rangeFlag', c_vp),
+                ('G', c_i32), ('M', c_i32), ('K', c_i32), ('N', c_i32), ('slope', c_f32)]
+
+
 class AffineBatchParams(ctypes.Structure):
     _fields_ = [('ws', c_vp), ('wsStrideN', c_i64), ('wsStrideL', c_i64), ('weight', c_vp), ('bias', c_vp), ('scale', c_vp),
                 ('rowStart', c_vp), ('wsIndex', c_vp), ('out', c_vp), ('N', c_i32), ('wDim', c_i32), ('layers', c_i32), ('rows', c_i32)]
@@ -129,6 +134,9 @@ EXPORTS = [
     ('sg3_affine_batch', ctypes.c_int, [ctypes.POINTER(AffineBatchParams), c_vp]),
     ('sg3_se_residual', ctypes.c_int, [ctypes.POINTER(SeParams), c_vp]),
     ('sg3_unfold3x3s2', ctypes.c_int, [ctypes.POINTER(UnfoldParams), c_vp]),
+    ('sg3_head_gemm_packed_halfs', ctypes.c_int64, [ctypes.c_int] * 3),
+    ('sg3_head_gemm_pack', ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
+    ('sg3_head_gemm', ctypes.c_int, [ctypes.POINTER(HeadGemmParams), c_vp]),
     ('sg3_modulation_backward', ctypes.c_int, [ctypes.POINTER(ModgradParams), c_vp]),
     ('sg3_modconv_transpose_weights', ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp]),
     ('sg3_modulated_conv2d_prep', ctypes.c_int, [ctypes.POINTER(ModconvPrepParams), c_vp]),
