@@ -35,7 +35,6 @@ constexpr int SE_MAXC = 2048, SE_MAXR = 128;
 
 __global__ void __launch_bounds__(256)
 se_apply_kernel(sg3_se_params p, int chunks) {
-    __shared__ float sm[SE_MAXC];
     __shared__ float sh[SE_MAXR];
     __shared__ float sg[SE_CG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -43,23 +42,28 @@ se_apply_kernel(sg3_se_params p, int chunks) {
     const int chunk = bid % chunks; bid /= chunks;
     const int groups = (p.C + SE_CG - 1) / SE_CG;
     const int cg = bid % groups, n = bid / groups;
-    for (int i = tid; i < p.C; i += 256) sm[i] = p.mean[(size_t)n * p.C + i];
-    __syncthreads();
+    // One round trip to memory for the whole gate computation: the means and the fc1 rows are read together (nothing between them
+    // waits on LDS), and every thread requests its fc2 entry before the barrier that publishes the hidden vector.
+    const float* mean = p.mean + (size_t)n * p.C;
+    const int gk = tid >> 5, gr = tid & 31;                                 // gate channel (SE_CG = 8 x 32 lanes) and hidden unit
+    const int gc = cg * SE_CG + gk;
+    const float f2 = (gc < p.C && gr < p.R) ? p.fc2[(size_t)gc * p.R + gr] : 0.f;
     for (int r = wave; r < p.R; r += 4) {                                   // hidden = relu(fc1 @ mean)
         const float* w = p.fc1 + (size_t)r * p.C;
         float s = 0.f;
-        for (int i = lane; i < p.C; i += 64) s = __builtin_fmaf(w[i], sm[i], s);
+        for (int i = lane; i < p.C; i += 64) s = __builtin_fmaf(w[i], mean[i], s);
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
         if (lane == 0) sh[r] = fmaxf(s, 0.f);
     }
     __syncthreads();
-    if (tid < SE_CG) {                                                      // gate = sigmoid(fc2 @ hidden)
-        const int c = cg * SE_CG + tid;
-        float s = 0.f;
-        if (c < p.C)
-            for (int r = 0; r < p.R; r++) s = __builtin_fmaf(p.fc2[(size_t)c * p.R + r], sh[r], s);
-        sg[tid] = 1.f / (1.f + expf(-s));
+    {                                                                       // gate = sigmoid(fc2 @ hidden): 32 lanes per channel
+        float s = gr < p.R ? f2 * sh[gr] : 0.f;
+        if (gc < p.C)
+            for (int r = gr + 32; r < p.R; r += 32) s = __builtin_fmaf(p.fc2[(size_t)gc * p.R + r], sh[r], s);
+#pragma unroll
+        for (int m = 16; m > 0; m >>= 1) s += __shfl_xor(s, m);
+        if (gr == 0) sg[gk] = 1.f / (1.f + expf(-s));
     }
     __syncthreads();
     const int hw = p.H * p.W;
