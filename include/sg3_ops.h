@@ -108,6 +108,9 @@ typedef struct sg3_filtered_lrelu_params {
                                  * radial filters design_lowpass_filter builds, networks_stylegan3.py:370-391).  The kernel then
                                  * adds the two samples that share a tap before multiplying: 42 instead of 72 packed operations per
                                  * upsampled row and lane.  0 = no assumption */
+    float*         yAbsMaxPartial; /* optional, readSigns calls only, same shape as ySumPartial: per-workgroup max |output|.  Their
+                                 * maximum is max |dx| of the adjoint pass: the operand bound the split-precision gradient kernels
+                                 * of the convolution in front need (sg3_conv2d_wgrad's amax mode), without a pass over dx */
 } sg3_filtered_lrelu_params;
 
 SG3_API int sg3_filtered_lrelu(const sg3_filtered_lrelu_params* p, void* stream);

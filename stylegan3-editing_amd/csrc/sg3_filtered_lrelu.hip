@@ -83,6 +83,8 @@ struct StreamParams {
     float gain, slope, clamp;
     int flip;
     float* ysum;                   // optional [N*C][nChunks*nStrips]: sum of this block's outputs (adjoint passes only: their bias gradient)
+    float* ymax;                   // optional, same shape: max |output| of this block (adjoint passes only: the operand bound of the
+                                   // convolution gradients that read the result next)
     unsigned char* s;              // sign tensor [N*C][sH][sWb] (2 bits per upsampled sample, 4 per byte), or null
     int sH, sWb, sx, sy;           // rows, bytes per row, offset of the upsampled buffer inside the sign tensor
 #ifdef SG3_STAMPS
@@ -259,6 +261,7 @@ struct WaveState {
     v2f tdP[Cfg::FD / 2];         // down taps (td[2m], td[2m+1]): V-down splats and H-down even/odd pairs
     unsigned sg[SG3_PREFETCH_ROWS][U];       // sign-read mode: prefetched sign bytes (this lane's byte | next byte << 8) per upsampled row
     float osum;                   // running sum of the outputs this lane stored (only kept when p.ysum is given)
+    float omax;                   // running max |output| (only kept when p.ymax is given)
     int soff;                     // sign modes: byte offset, inside a sign row, of the byte holding this lane's first column
     int sq;                       // sign modes: position (0..3) of that column inside its byte (wave-uniform)
     int inBase, outBase;          // packed mode: this lane's window start in the input LDS row / its 4 samples' place in the output LDS row
@@ -544,7 +547,11 @@ struct Stream {
                     if (oy >= oy0 && oy < oy1) {                   // wave-uniform
                         const v2f y0 = st.acc[headR][0], y1 = st.acc[headR][1];
                         const float f0 = (y0.x + y0.y) * gainOut, f1 = (y1.x + y1.y) * gainOut;
-                        if (SIGNS == 2) st.osum += (2 * lane < oxN ? f0 : 0.f) + (2 * lane + 1 < oxN ? f1 : 0.f);
+                        if (SIGNS == 2) {
+                            const float m0 = 2 * lane < oxN ? f0 : 0.f, m1 = 2 * lane + 1 < oxN ? f1 : 0.f;
+                            st.osum += m0 + m1;
+                            st.omax = __builtin_fmaxf(st.omax, __builtin_fmaxf(__builtin_fabsf(m0), __builtin_fabsf(m1)));
+                        }
                         T* orow = oplane + (long long)oy * p.ysH + ox0;
                         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)orow, (short)0, (G > 1 ? (int)p.ysC + oxN : oxN) * (int)sizeof(T), 0x00020000);
                         if (pairStore) {
@@ -594,7 +601,11 @@ struct Stream {
 #pragma unroll
                         for (int q = 1; q < Cfg::FD / 2; q++) { y0 = fma2(pr[q], st.tdP[q], y0); y1 = fma2(pr[q + 1], st.tdP[q], y1); }
                         const float f0 = (y0.x + y0.y) * gainOut, f1 = (y1.x + y1.y) * gainOut;
-                        if (SIGNS == 2) st.osum += (2 * lane < oxN ? f0 : 0.f) + (2 * lane + 1 < oxN ? f1 : 0.f);
+                        if (SIGNS == 2) {
+                            const float m0 = 2 * lane < oxN ? f0 : 0.f, m1 = 2 * lane + 1 < oxN ? f1 : 0.f;
+                            st.osum += m0 + m1;
+                            st.omax = __builtin_fmaxf(st.omax, __builtin_fmaxf(__builtin_fabsf(m0), __builtin_fabsf(m1)));
+                        }
 #ifdef SG3_FUSION_BOUND
                         // diagnostic builds of tools/flrelu_fusion_bound.hip ONLY (never in the product library): what a fusion of this
                         // layer with the ToRGB convolution behind it could cost at least.  1: the activation plane is not stored at all
@@ -626,7 +637,11 @@ struct Stream {
 #pragma unroll
                         for (int q = 1; q < Cfg::FD / 2; q++) y0 = fma2(pr[q], st.tdP[q], y0);
                         const float f0 = (y0.x + y0.y) * gainOut;
-                        if (SIGNS == 2) st.osum += lane < oxN ? f0 : 0.f;
+                        if (SIGNS == 2) {
+                            const float m0 = lane < oxN ? f0 : 0.f;
+                            st.osum += m0;
+                            st.omax = __builtin_fmaxf(st.omax, __builtin_fabsf(m0));
+                        }
                         bufio<T>::st1(rs, lane * (int)sizeof(T), f0);
                     }
                     wave_lds_sync();
@@ -739,6 +754,7 @@ struct Stream {
         }
 
         st.osum = 0.f;
+        st.omax = 0.f;
         float liveGain = p.gain;                  // the output gain; NaN from the row on in which this wave staged a non-finite sample
         float liveGain1 = p.gain;                 // packed mode: the second plane's
         if (SIGNS) {
@@ -794,6 +810,12 @@ struct Stream {
 #pragma unroll
             for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
             if (lane == 0) p.ysum[(long long)plane_id * (p.nChunks * p.nStrips) + chunk * p.nStrips + strip] = v;
+        }
+        if (SIGNS == 2 && p.ymax) {                         // max |dx| of the adjoint pass
+            float v = st.omax;
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, m));
+            if (lane == 0) p.ymax[(long long)plane_id * (p.nChunks * p.nStrips) + chunk * p.nStrips + strip] = v;
         }
     }
 };
@@ -915,6 +937,7 @@ static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
 
     p.s = q.s; p.sH = q.sH; p.sWb = q.sWbytes; p.sx = q.sx; p.sy = q.sy;
     p.ysum = q.ySumPartial;
+    p.ymax = q.yAbsMaxPartial;
 #ifdef SG3_STAMPS
     p.stamps = g_stamps;
 #endif

@@ -41,13 +41,24 @@ def _mirror_symmetric(f):
     return same
 
 
+def _no_kernel(return_sum, return_amax=False):
+    base = (torch.empty(0), torch.empty(0), -1)
+    if return_sum:
+        base = base + (None,)
+        if return_amax:
+            base = base + (None,)
+    return base
+
+
 class FilteredLreluPlugin:
     name = 'filtered_lrelu_plugin'
 
     @staticmethod
-    def filtered_lrelu(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, slope, clamp, flip_filters, writeSigns, return_sum=False):
+    def filtered_lrelu(x, fu, fd, b, si, up, down, px0, px1, py0, py1, sx, sy, gain, slope, clamp, flip_filters, writeSigns, return_sum=False, return_amax=False):
         """-> (y, so, return_code).  return_code -1 (with empty tensors) = no fused kernel for this configuration.
-        `return_sum` (extension): also return y.sum([0,2,3]) per channel, accumulated by the kernel (-> (y, so, rc, ysum))."""
+        `return_sum` (extension): also return y.sum([0,2,3]) per channel, accumulated by the kernel (-> (y, so, rc, ysum));
+        with `return_amax` besides: max |y| as a one-element float32 tensor, from the same launch (-> (y, so, rc, ysum, amax); None
+        when the kernel did not accumulate it)."""
         _require(x.is_cuda, 'x must reside on CUDA device')
         _require(fu.device == x.device and fd.device == x.device and b.device == x.device, 'all input tensors must reside on the same device')
         _require(fu.dtype == torch.float32 and fd.dtype == torch.float32, 'fu and fd must be float32')
@@ -65,7 +76,7 @@ class FilteredLreluPlugin:
         fuW, fuH = int(fu.shape[-1]), (int(fu.shape[0]) if fu.ndim == 2 else 0)
         fdW, fdH = int(fd.shape[-1]), (int(fd.shape[0]) if fd.ndim == 2 else 0)
         if not lib.sg3_filtered_lrelu_has_kernel(int(up), int(down), fuW, fuH, fdW, fdH):
-            return (torch.empty(0), torch.empty(0), -1, None) if return_sum else (torch.empty(0), torch.empty(0), -1)
+            return _no_kernel(return_sum, return_amax)
 
         N, C, xH, xW = (int(v) for v in x.shape)
         yH, yW, sH, sWb, swl = (ctypes.c_int() for _ in range(5))
@@ -107,20 +118,26 @@ class FilteredLreluPlugin:
         p.gain, p.slope, p.clamp = float(gain), float(slope), float(clamp)
         p.flip, p.writeSigns, p.readSigns = int(bool(flip_filters)), int(bool(writeSigns)), int(bool(readSigns))
         p.fdMirror = int(fd.ndim == 2 and fd.shape[0] > 1 and _mirror_symmetric(fd))
-        partial = None
+        partial = partial_max = None
         if return_sum:
             slots = int(lib.sg3_filtered_lrelu_sum_slots(N, C, yH.value, yW.value, int(down)))
             if slots > 0:
                 partial = torch.empty([N, C, slots], dtype=torch.float32, device=x.device)
                 p.ySumPartial = abi.ptr(partial)
+                if return_amax:
+                    partial_max = torch.empty([N, C, slots], dtype=torch.float32, device=x.device)
+                    p.yAbsMaxPartial = abi.ptr(partial_max)
         if planes_per_wave_log is not None:            # tests: which form of the streaming kernel this call takes (host-only query)
             planes_per_wave_log.append(int(lib.sg3_filtered_lrelu_planes_per_wave(ctypes.byref(p))))
         with torch.cuda.device(x.device):
             rc = lib.sg3_filtered_lrelu(ctypes.byref(p), abi.stream_ptr(x.device))
         if abi.check(rc, 'sg3_filtered_lrelu', allow_no_kernel=True) == abi.SG3_NO_KERNEL:
-            return (torch.empty(0), torch.empty(0), -1, None) if return_sum else (torch.empty(0), torch.empty(0), -1)
+            return _no_kernel(return_sum, return_amax)
         if return_sum:
-            return y, so, 0, (partial.sum(dim=(0, 2)).to(x.dtype) if partial is not None else None)
+            ysum = partial.sum(dim=(0, 2)).to(x.dtype) if partial is not None else None
+            if return_amax:
+                return y, so, 0, ysum, (partial_max.max().reshape(1) if partial_max is not None else None)
+            return y, so, 0, ysum
         return y, so, 0
 
     @staticmethod

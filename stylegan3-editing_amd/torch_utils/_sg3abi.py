@@ -28,7 +28,7 @@ class FilteredLreluParams(ctypes.Structure):
                 ('up', c_i32), ('down', c_i32), ('fuW', c_i32), ('fuH', c_i32), ('fdW', c_i32), ('fdH', c_i32),
                 ('px0', c_i32), ('py0', c_i32), ('sH', c_i32), ('sWbytes', c_i32), ('sx', c_i32), ('sy', c_i32),
                 ('swLimit', c_i32), ('gain', c_f32), ('slope', c_f32), ('clamp', c_f32),
-                ('flip', c_i32), ('writeSigns', c_i32), ('readSigns', c_i32), ('ySumPartial', c_vp), ('fdMirror', c_i32)]
+                ('flip', c_i32), ('writeSigns', c_i32), ('readSigns', c_i32), ('ySumPartial', c_vp), ('fdMirror', c_i32), ('yAbsMaxPartial', c_vp)]
 
 
 class FilteredLreluActParams(ctypes.Structure):

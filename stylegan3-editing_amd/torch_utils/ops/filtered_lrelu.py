@@ -20,6 +20,7 @@ from collections import namedtuple
 import torch
 
 from . import bias_act
+from . import known_amax
 from . import upfirdn2d
 from ._resample_args import fir_extent, four_sided
 from .. import custom_ops
@@ -169,9 +170,11 @@ class _FusedFlrelu(torch.autograd.Function):
                 zero_b = torch.zeros([dy.shape[1]], dtype=dy.dtype, device=dy.device)
                 res = _plugin.filtered_lrelu(dy.contiguous(), fd, fu, zero_b, signs, adj.up, adj.down,
                                              adj.px0, adj.px1, adj.py0, adj.py1, sx, sy, adj.gain, adj.slope,
-                                             adj.clamp, adj.flip, False, return_sum=want_b)
-                if res[2] == 0:                     # (y, signs, code) and, with return_sum, the per-channel sums
+                                             adj.clamp, adj.flip, False, return_sum=True, return_amax=True)
+                if res[2] == 0:                     # (y, signs, code, per-channel sums, max |y|)
                     dx, db = res[0], (res[3] if want_b else None)
+                    if res[4] is not None:
+                        known_amax.attach(dx, res[4])     # the convolution in front scales its gradient operands by it
             if dx is None:
                 dx = _FusedFlrelu.apply(dy, fd, fu, None, adj, signs, sx, sy)
             if want_b and db is None:

@@ -24,6 +24,7 @@ import torch
 
 from .. import _sg3abi as abi
 from .. import misc
+from . import known_amax
 
 # Arithmetic of the implicit GEMM when the caller supplies a bound on |x| (`x_bound`):
 #   'f16x3' : fp16 hi/lo operand split, three fp16 MFMAs per K step, fp32 accumulation (fp32-equivalent: every
@@ -380,8 +381,10 @@ class _ModulatedConv2dHip(torch.autograd.Function):
             for j, gr in zip(idx, grads):
                 out[j] = gr
             return tuple(out)
+        dy_amax = known_amax.lookup(dy)                       # left by the adjoint filtered_lrelu launch that wrote dy, if it did
         dy = dy.contiguous()
-        dy_amax = _amax(dy)                                   # shared by both gradient kernels' operand scaling
+        if dy_amax is None:
+            dy_amax = _amax(dy)                               # shared by both gradient kernels' operand scaling
         n = int(x.shape[0])
         co, ci, k, _ = (int(v) for v in w.shape)
         if need[0]:

@@ -828,3 +828,71 @@ def test_transposed_weights_kernel_matches_the_torch_ops(co, ci, k, norm):
     got = mc._transposed_weights(w, norm)
     assert tuple(got.shape) == (ci, co, k, k)
     assert maxabs(got.cpu().numpy(), ref.cpu().numpy()) <= 2e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize('shape,up,taps,pad,radial', [
+    ((1, 2, 150, 150), 2, 12, [9, 8, 9, 8], False),           # T up-2 (adjoint: up 2 / down 2)
+    ((2, 3, 86, 86), 4, 24, [-6, -9, -6, -9], False),          # T up-4 (adjoint: up 2 / down 4, one column per lane)
+    ((1, 2, 84, 150), 2, 12, [11, 10, 11, 10], True),          # R up-2 (adjoint: 12x12 up filter)
+    ((1, 1, 278, 130), 2, 12, [9, 8, 9, 8], False),            # several row chunks
+])
+def test_filtered_lrelu_adjoint_hands_max_abs_dx_to_the_convolution_gradients(shape, up, taps, pad, radial):
+    """The adjoint launch keeps max |dx| of what it stores (yAbsMaxPartial) and attaches it to dx (torch_utils/ops/known_amax.py):
+    exactly dx.abs().max(); the lookup misses after an in-place change, on a view with another address, and when switched off."""
+    from oracle import oracle as O
+    from torch_utils.ops import filtered_lrelu as fl, known_amax
+    fl._init()
+    fu = O.design_lowpass_filter(taps, 4.0, 8.0, 64.0 * up / 2)
+    fd = O.design_lowpass_filter(12, 5.0, 9.0, 64.0, radial=radial)
+    x = T(rand(3, *shape)).requires_grad_(True); b = T(rand(4, shape[1])).requires_grad_(True)
+    y = fl.filtered_lrelu(x, T(fu), T(fd), b, up=up, down=2, padding=pad, gain=float(np.sqrt(2)), slope=0.2, clamp=256, flip_filter=False)
+    seen = {}
+
+    def hook(g):                                                        # g: what the adjoint's backward returned for x
+        seen['amax'] = known_amax.lookup(g)
+
+    x.register_hook(hook)
+    (y * T(rand(5, *y.shape)) * 37.0).sum().backward()
+    assert seen['amax'] is not None, 'the adjoint kernel did not attach max |dx|'
+    assert float(seen['amax']) == float(x.grad.abs().max())
+    g = x.grad
+    known_amax.attach(g, seen['amax'])
+    assert known_amax.lookup(g) is seen['amax']
+    assert known_amax.lookup(g[:, :, 1:]) is None                       # another tensor object
+    saved, known_amax.enabled = known_amax.enabled, False
+    try:
+        assert known_amax.lookup(g) is None
+    finally:
+        known_amax.enabled = saved
+    g.mul_(2.0)                                                         # an in-place change invalidates it
+    assert known_amax.lookup(g) is None
+
+
+def test_known_amax_reaches_the_modulated_convolution_backward_and_changes_nothing():
+    """conv -> filtered_lrelu as SynthesisLayer chains them (networks_stylegan3.py:335-368): the convolution's backward finds the
+    bound the adjoint launch left on dy (no reduction pass of its own), and every gradient is bit-identical to the run with the
+    hand-off switched off."""
+    from oracle import oracle as O
+    from torch_utils.ops import filtered_lrelu as fl, known_amax
+    from torch_utils.ops.modulated_conv import modulated_conv2d
+    fl._init()
+    fu = T(O.design_lowpass_filter(12, 4.0, 8.0, 64.0)); fd = T(O.design_lowpass_filter(12, 5.0, 9.0, 64.0))
+    xn, wn, sn, bn = rand(1, 2, 48, 60, 60), rand(2, 64, 48, 3, 3), rand(3, 2, 48) + 1.5, rand(4, 64)
+
+    def run():
+        x = T(xn).requires_grad_(True); w = T(wn).requires_grad_(True); s = T(sn).requires_grad_(True); b = T(bn).requires_grad_(True)
+        h = modulated_conv2d(x=x, w=w, s=s, padding=2, demodulate=True)
+        y = fl.filtered_lrelu(h, fu, fd, b, up=2, down=2, padding=[9, 8, 9, 8], gain=float(np.sqrt(2)), slope=0.2, clamp=256)
+        (y * y).sum().backward()
+        return [t.grad.clone() for t in (x, w, s, b)]
+
+    h0 = known_amax.hits
+    with_it = run()
+    assert known_amax.hits == h0 + 1, 'the convolution backward did not find the attached bound'
+    saved, known_amax.enabled = known_amax.enabled, False
+    try:
+        without = run()
+    finally:
+        known_amax.enabled = saved
+    for a, c in zip(with_it, without):
+        assert torch.equal(a, c)

@@ -7,8 +7,12 @@ import torch, warnings  # noqa: E402
 from helpers import build_product_generator  # noqa: E402
 from synth_weights import synth_ws  # noqa: E402
 ap = argparse.ArgumentParser(); ap.add_argument('cfg'); ap.add_argument('--batch', type=int, default=1); ap.add_argument('--iters', type=int, default=3)
+ap.add_argument('--own-amax', action='store_true', help='the convolution gradients reduce max |dy| themselves (A/B of torch_utils/ops/known_amax.py)')
 a = ap.parse_args()
 warnings.simplefilter('ignore')
+if a.own_amax:
+    from torch_utils.ops import known_amax
+    known_amax.enabled = False
 G = build_product_generator(a.cfg, device='cuda:0'); G.requires_grad_(True)
 opt = torch.optim.Adam(list(G.synthesis.parameters())[3:], lr=3e-4)
 ws = torch.from_numpy(synth_ws(a.batch, G.num_ws, G.w_dim, 1)).cuda()
@@ -23,4 +27,6 @@ for _ in range(a.iters):
     step()
 torch.cuda.synchronize()
 dt = (time.time() - t) / a.iters
+from torch_utils.ops import known_amax as _ka  # noqa: E402
+print(f'known_amax hits {_ka.hits}', end='  ')
 print(f'{a.cfg} PTI batch {a.batch}: {dt * 1e3:.1f} ms/step  {a.batch / dt:.2f} frames/s  peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB')
