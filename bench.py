@@ -272,7 +272,7 @@ def bench_pti_step(device, cfg='T1024', steps=4, timer=None):
     from synth_weights import synth_ws
     G = build_generator(cfg, device)
     G.requires_grad_(True)
-    opt = torch.optim.Adam(list(G.synthesis.parameters())[3:], lr=3e-4)
+    opt = torch.optim.Adam(list(G.synthesis.parameters())[3:], lr=3e-4, fused=True)      # as PivotalTuning.get_optimizer builds it on a GPU
     w = torch.from_numpy(synth_ws(1, G.num_ws, G.w_dim, seed=3)).to(device)
     target = torch.zeros(1, 3, G.img_resolution, G.img_resolution, device=device)
 

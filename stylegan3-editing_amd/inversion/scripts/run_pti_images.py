@@ -52,7 +52,12 @@ class PTI:
         return tunable
 
     def get_optimizer(self, generator):
-        return torch.optim.Adam(self.tunable_parameters(generator), lr=self.opts.learning_rate)
+        """Adam(lr) over the tunable parameters, as the reference (:111-116).  On a GPU the update of all ~100 tensors is ONE fused
+        multi-tensor launch (`fused=True`: the same update rule; the default builds it from ~12 launches per step, 0.4 ms of a
+        14 ms step at FFHQ-1024)."""
+        params = self.tunable_parameters(generator)
+        fused = all(p.is_cuda and p.dtype == torch.float32 for p in params)
+        return torch.optim.Adam(params, lr=self.opts.learning_rate, **(dict(fused=True) if fused else {}))
 
     def optimize_model(self, generator, codes, target_images, landmarks_transforms=None, image_name=None):
         optimizer = self.get_optimizer(generator)

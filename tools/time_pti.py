@@ -7,6 +7,7 @@ import torch, warnings  # noqa: E402
 from helpers import build_product_generator  # noqa: E402
 from synth_weights import synth_ws  # noqa: E402
 ap = argparse.ArgumentParser(); ap.add_argument('cfg'); ap.add_argument('--batch', type=int, default=1); ap.add_argument('--iters', type=int, default=3)
+ap.add_argument('--fused-adam', action='store_true', help='torch.optim.Adam(fused=True): one multi-tensor launch per step instead of ~12')
 ap.add_argument('--own-amax', action='store_true', help='the convolution gradients reduce max |dy| themselves (A/B of torch_utils/ops/known_amax.py)')
 a = ap.parse_args()
 warnings.simplefilter('ignore')
@@ -14,7 +15,7 @@ if a.own_amax:
     from torch_utils.ops import known_amax
     known_amax.enabled = False
 G = build_product_generator(a.cfg, device='cuda:0'); G.requires_grad_(True)
-opt = torch.optim.Adam(list(G.synthesis.parameters())[3:], lr=3e-4)
+opt = torch.optim.Adam(list(G.synthesis.parameters())[3:], lr=3e-4, **(dict(fused=True) if a.fused_adam else {}))
 ws = torch.from_numpy(synth_ws(a.batch, G.num_ws, G.w_dim, 1)).cuda()
 target = torch.zeros(a.batch, 3, G.img_resolution, G.img_resolution, device='cuda')
 def step():
