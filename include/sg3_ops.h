@@ -118,6 +118,11 @@ SG3_API int sg3_filtered_lrelu(const sg3_filtered_lrelu_params* p, void* stream)
 /* number of partial sums per (n,c) plane that sg3_filtered_lrelu writes to ySumPartial for this output shape */
 SG3_API int sg3_filtered_lrelu_sum_slots(int N, int C, int yH, int yW, int down);
 
+/* db[c] = sum over (n, slot) of sumPartial[n][c][slot] (float32 [C]) and, when given, absMax[0] = max over absMaxPartial: the
+ * per-workgroup values of one readSigns call folded in one small launch (fixed summation order) */
+SG3_API int sg3_filtered_lrelu_finish_partials(const float* sumPartial, const float* absMaxPartial, int N, int C, int slots,
+                                               float* db, float* absMax, void* stream);
+
 /* Host-only query: how many (n,c) planes one wave of the streaming kernel works on for this call -- 2 for the plain forward on
  * narrow dense planes (output at most 54 columns wide, even C: the 36^2 .. 52^2 layers); 3 = mixed: rows cut into 120-column
  * strips with one plane per wave plus a remainder strip of at most 54 columns with two (the 148^2 .. 532^2 layers); 1 otherwise;

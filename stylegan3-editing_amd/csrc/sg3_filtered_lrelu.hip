@@ -924,6 +924,33 @@ static int stream_full_strips(int yW, int nStripsEqual) {
     return (nFull >= 1 && nFull + 1 == nStripsEqual && rem <= StreamCfg<2, 2>::PACKTW) ? nFull : 0;
 }
 
+// The per-workgroup partial sums / maxima an adjoint launch left ([N][C][slots] each) -> the bias gradient db[c] = sum over (n, slot)
+// and max |dx| = max over everything, in one small launch (as torch ops: a strided reduction and a max, ~19 us per layer and PTI step).
+// One block: thread per channel, (n, slot) walked in order -- a fixed summation order, so db is reproducible.
+__global__ void __launch_bounds__(256)
+flrelu_finish_partials_kernel(const float* __restrict__ psum, const float* __restrict__ pmax, int N, int C, int slots,
+                              float* __restrict__ db, float* __restrict__ amax) {
+    __shared__ float red[4];
+    float mx = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int n = 0; n < N; n++) {
+            const size_t base = ((size_t)n * C + c) * slots;
+            for (int k = 0; k < slots; k++) {
+                s += psum[base + k];
+                if (pmax) mx = __builtin_fmaxf(mx, pmax[base + k]);
+            }
+        }
+        db[c] = s;
+    }
+    if (!amax) return;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, m));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) amax[0] = __builtin_fmaxf(__builtin_fmaxf(red[0], red[1]), __builtin_fmaxf(red[2], red[3]));
+}
+
 template <typename T>
 static int launch_stream(const sg3_filtered_lrelu_params& q, hipStream_t st) {
     StreamParams p;
@@ -1057,6 +1084,15 @@ int sg3_filtered_lrelu_sum_slots(int N, int C, int yH, int yW, int down) {
     int nStrips, TW, nChunks, CH;
     sg3::stream_grid(N, C, yH, yW, down, nStrips, TW, nChunks, CH);
     return nStrips * nChunks;
+}
+
+int sg3_filtered_lrelu_finish_partials(const float* sumPartial, const float* absMaxPartial, int N, int C, int slots, float* db, float* absMax, void* stream) {
+    using namespace sg3;
+    SG3_REQUIRE(sumPartial && db && N > 0 && C > 0 && slots > 0, "filtered_lrelu_finish_partials: bad arguments");
+    SG3_REQUIRE(!absMax == !absMaxPartial, "filtered_lrelu_finish_partials: absMaxPartial and absMax come together");
+    hipLaunchKernelGGL(flrelu_finish_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sumPartial, absMaxPartial, N, C, slots, db, absMax);
+    SG3_LAUNCH_CHECK("flrelu_finish_partials_kernel");
+    return SG3_OK;
 }
 
 int sg3_filtered_lrelu_shape(int xH, int xW, int up, int down, int fuW, int fuH, int fdW, int fdH,

@@ -134,10 +134,16 @@ class FilteredLreluPlugin:
         if abi.check(rc, 'sg3_filtered_lrelu', allow_no_kernel=True) == abi.SG3_NO_KERNEL:
             return _no_kernel(return_sum, return_amax)
         if return_sum:
-            ysum = partial.sum(dim=(0, 2)).to(x.dtype) if partial is not None else None
-            if return_amax:
-                return y, so, 0, ysum, (partial_max.max().reshape(1) if partial_max is not None else None)
-            return y, so, 0, ysum
+            ysum = amax = None
+            if partial is not None:                    # fold the per-workgroup values: one small launch for both
+                ysum = torch.empty([C], dtype=torch.float32, device=x.device)
+                amax = torch.empty([1], dtype=torch.float32, device=x.device) if partial_max is not None else None
+                with torch.cuda.device(x.device):
+                    abi.check(lib.sg3_filtered_lrelu_finish_partials(abi.ptr(partial), abi.ptr(partial_max) if partial_max is not None else None,
+                                                                     N, C, int(partial.shape[2]), abi.ptr(ysum), abi.ptr(amax) if amax is not None else None,
+                                                                     abi.stream_ptr(x.device)), 'sg3_filtered_lrelu_finish_partials')
+                ysum = ysum.to(x.dtype)
+            return (y, so, 0, ysum, amax) if return_amax else (y, so, 0, ysum)
         return y, so, 0
 
     @staticmethod

@@ -120,6 +120,7 @@ EXPORTS = [
     ('sg3_filtered_lrelu_planes_per_wave', ctypes.c_int, [ctypes.POINTER(FilteredLreluParams)]),
     ('sg3_filtered_lrelu_has_kernel', ctypes.c_int, [ctypes.c_int] * 6),
     ('sg3_filtered_lrelu_sum_slots', ctypes.c_int, [ctypes.c_int] * 5),
+    ('sg3_filtered_lrelu_finish_partials', ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp]),
     ('sg3_filtered_lrelu_shape', ctypes.c_int, [ctypes.c_int] * 12 + [ctypes.POINTER(ctypes.c_int)] * 5),
     ('sg3_filtered_lrelu_act', ctypes.c_int, [ctypes.POINTER(FilteredLreluActParams), c_vp]),
     ('sg3_upfirdn2d', ctypes.c_int, [ctypes.POINTER(Upfirdn2dParams), c_vp]),

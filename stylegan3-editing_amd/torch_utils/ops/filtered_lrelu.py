@@ -125,6 +125,18 @@ def _adjoint(cfg, fu, fd, x_hw, y_hw, sx, sy):
     return adj, sx - (fu_w - 1) + cfg.px0, sy - (fu_h - 1) + cfg.py0
 
 
+_zero_biases = {}
+
+
+def _zero_bias(c, dtype, device):
+    """A [c] vector of zeros (the adjoint pass has no bias), made once per (c, dtype, device): kernels only read it."""
+    key = (c, dtype, str(device))
+    z = _zero_biases.get(key)
+    if z is None:
+        z = _zero_biases[key] = torch.zeros([c], dtype=dtype, device=device)
+    return z
+
+
 class _FusedFlrelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, fu, fd, b, cfg, si, sx, sy):  # pylint: disable=arguments-differ
@@ -167,7 +179,7 @@ class _FusedFlrelu(torch.autograd.Function):
             if not torch.is_grad_enabled() and dy.dtype in (torch.float16, torch.float32):
                 # first-order gradients: the fused adjoint kernel also accumulates the per-channel sum of dx, so the
                 # bias gradient needs no second pass over dx
-                zero_b = torch.zeros([dy.shape[1]], dtype=dy.dtype, device=dy.device)
+                zero_b = _zero_bias(int(dy.shape[1]), dy.dtype, dy.device)
                 res = _plugin.filtered_lrelu(dy.contiguous(), fd, fu, zero_b, signs, adj.up, adj.down,
                                              adj.px0, adj.px1, adj.py0, adj.py1, sx, sy, adj.gain, adj.slope,
                                              adj.clamp, adj.flip, False, return_sum=True, return_amax=True)
