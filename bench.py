@@ -272,7 +272,8 @@ def bench_pti_step(device, cfg='T1024', steps=4, timer=None):
     from synth_weights import synth_ws
     G = build_generator(cfg, device)
     G.requires_grad_(True)
-    opt = torch.optim.Adam(list(G.synthesis.parameters())[3:], lr=3e-4, fused=True)      # as PivotalTuning.get_optimizer builds it on a GPU
+    from inversion.scripts.run_pti_images import tuning_optimizer
+    opt = tuning_optimizer(list(G.synthesis.parameters())[3:], lr=3e-4)      # Adam as PTI.get_optimizer builds it: one fused launch on a GPU
     w = torch.from_numpy(synth_ws(1, G.num_ws, G.w_dim, seed=3)).to(device)
     target = torch.zeros(1, 3, G.img_resolution, G.img_resolution, device=device)
 

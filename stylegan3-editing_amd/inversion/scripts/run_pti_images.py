@@ -16,6 +16,28 @@ import torch
 from torch import nn
 
 
+class _FusedAdam(torch.optim.Adam):
+    """torch.optim.Adam(fused=True) -- the update of all tensors in ONE multi-tensor launch -- that still tells the rest of the
+    process that the weights changed: the fused update does not advance the parameters' version counters (torch 2.10), and the
+    generator's inference caches (packed convolution weights, affine packs; keyed by address and version) and the graphs'
+    staleness check would keep serving the weights from before the step."""
+
+    def step(self, closure=None):
+        out = super().step(closure)
+        for group in self.param_groups:
+            torch.autograd.graph.increment_version(group['params'])
+        return out
+
+
+def tuning_optimizer(params, lr):
+    """The reference's `torch.optim.Adam(params, lr=lr)` (run_pti_images.py:111-116); fused into one launch per step when every
+    parameter is a float32 GPU tensor (0.4 ms of a 14 ms step at FFHQ-1024), the default implementation otherwise."""
+    params = list(params)
+    if params and all(p.is_cuda and p.dtype == torch.float32 for p in params):
+        return _FusedAdam(params, lr=lr, fused=True)
+    return torch.optim.Adam(params, lr=lr)
+
+
 def default_opts(**overrides):
     """Defaults of the reference RunConfig (:25-60) that the optimisation itself reads."""
     o = types.SimpleNamespace(device='cuda', steps=350, learning_rate=3e-4, lpips_lambda=1.0, l2_lambda=1.0,
@@ -52,12 +74,8 @@ class PTI:
         return tunable
 
     def get_optimizer(self, generator):
-        """Adam(lr) over the tunable parameters, as the reference (:111-116).  On a GPU the update of all ~100 tensors is ONE fused
-        multi-tensor launch (`fused=True`: the same update rule; the default builds it from ~12 launches per step, 0.4 ms of a
-        14 ms step at FFHQ-1024)."""
-        params = self.tunable_parameters(generator)
-        fused = all(p.is_cuda and p.dtype == torch.float32 for p in params)
-        return torch.optim.Adam(params, lr=self.opts.learning_rate, **(dict(fused=True) if fused else {}))
+        """Adam(lr) over the tunable parameters, as the reference (:111-116); see `tuning_optimizer`."""
+        return tuning_optimizer(self.tunable_parameters(generator), self.opts.learning_rate)
 
     def optimize_model(self, generator, codes, target_images, landmarks_transforms=None, image_name=None):
         optimizer = self.get_optimizer(generator)

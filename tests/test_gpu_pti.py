@@ -140,3 +140,34 @@ def test_pti_step_at_full_size(cfg):
     with torch.no_grad():
         after = torch.nn.functional.mse_loss(G.synthesis(w, noise_mode='const', force_fp32=True), target).item()
     assert after < loss.item(), (after, loss.item())
+
+
+def test_fused_adam_step_advances_the_version_counters_the_inference_caches_key_on():
+    """`tuning_optimizer` fuses Adam into one launch on a GPU; torch's fused update leaves the parameters' version counters alone, so
+    the subclass advances them -- otherwise the packed-weight caches of the inference path (and the graphs' staleness check) would
+    keep serving the weights from before the step.  Checked end to end: inference, one tuning step, inference again == the same
+    weights loaded into a fresh generator."""
+    from helpers import build_product_generator
+    from inversion.scripts.run_pti_images import tuning_optimizer
+    G = build_product_generator('Tmini', device=DEV)
+    ws = torch.from_numpy(np.random.RandomState(2).randn(1, G.num_ws, G.w_dim).astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        before = G.synthesis(ws, noise_mode='const', force_fp32=True).clone()          # fills the inference caches
+    G.requires_grad_(True)
+    params = list(G.synthesis.parameters())[3:]
+    opt = tuning_optimizer(params, lr=1e-2)
+    assert type(opt).__name__ == '_FusedAdam'
+    versions = [p._version for p in params]
+    out = G.synthesis(ws, noise_mode='const', force_fp32=True)
+    out.square().mean().backward()
+    opt.step()
+    assert all(p._version > v for p, v in zip(params, versions))
+    G.requires_grad_(False)
+    with torch.no_grad():
+        after = G.synthesis(ws, noise_mode='const', force_fp32=True)
+    fresh = build_product_generator('Tmini', device=DEV)
+    fresh.load_state_dict(G.state_dict())
+    with torch.no_grad():
+        ref = fresh.synthesis(ws, noise_mode='const', force_fp32=True)
+    assert float((after - before).abs().max()) > 1e-4                                  # the step did change the image
+    assert float((after - ref).abs().max()) <= 1e-5

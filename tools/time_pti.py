@@ -15,7 +15,11 @@ if a.own_amax:
     from torch_utils.ops import known_amax
     known_amax.enabled = False
 G = build_product_generator(a.cfg, device='cuda:0'); G.requires_grad_(True)
-opt = torch.optim.Adam(list(G.synthesis.parameters())[3:], lr=3e-4, **(dict(fused=True) if a.fused_adam else {}))
+if a.fused_adam:
+    from inversion.scripts.run_pti_images import tuning_optimizer
+    opt = tuning_optimizer(list(G.synthesis.parameters())[3:], lr=3e-4)
+else:
+    opt = torch.optim.Adam(list(G.synthesis.parameters())[3:], lr=3e-4)
 ws = torch.from_numpy(synth_ws(a.batch, G.num_ws, G.w_dim, 1)).cuda()
 target = torch.zeros(a.batch, 3, G.img_resolution, G.img_resolution, device='cuda')
 def step():
