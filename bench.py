@@ -266,7 +266,7 @@ def bench_inversion(G, device, rank, world, frames_per_gpu=16, restyle_steps=5, 
                          'ranks, all-gather of [F,16,512] latents; synthetic weights')
 
 
-def bench_pti_step(device, cfg='T1024', steps=4, timer=None):
+def bench_pti_step(device, cfg='T1024', steps=8, timer=None):
     """One pivotal-tuning step (reference run_pti_images.py:126-139): fp32 synthesis forward with sign write, MSE, backward
     through the fused adjoint / gradient kernels, Adam over the synthesis weights; batch 1, FFHQ-1024."""
     from synth_weights import synth_ws
@@ -283,7 +283,8 @@ def bench_pti_step(device, cfg='T1024', steps=4, timer=None):
         opt.zero_grad()
         loss.backward()
         opt.step()
-    step()
+    for _ in range(3):                      # the first steps also size the allocator's pools and Adam's state
+        step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
