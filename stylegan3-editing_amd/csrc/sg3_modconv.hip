@@ -55,6 +55,7 @@ struct ConvParams {
     int outPitch;                    // elements between output rows (row-streaming 3x3 kernel; elsewhere = outW)
     int tailPack;                    // row-streaming 3x3 kernel: the last K chunk holds at most 4 channels (see the kernel)
     const float* epBias; float epClamp, epScale;     // ToRGB kernel only: out = clamp(conv + bias[o]) * scale (see sg3_modconv_params)
+    int kSplits; float* partial;     // flat 3x3 kernel only: input channels split over kSplits workgroups per tile, raw sums to partial
 };
 
 template <typename T, int KS, int WM, int WN, int TM, int TN>
@@ -539,6 +540,11 @@ modconv_flat_kernel(ConvParams p) {
         const int nb = p.totalBlocks, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
+    // Small grids (batch 1 on the 36^2 maps: 96 tiles for 256 CUs, each walking all 32 K chunks with nobody to hide its latency):
+    // the K chunks of a tile are split over kSplits workgroups, innermost in the block order so that they run side by side; each
+    // writes its raw sums to partial[ks] and modconv_split_reduce_kernel adds them in order and applies the demodulation.
+    const int ks = bid % p.kSplits; bid /= p.kSplits;
+    const int chBegin = (int)((long long)ks * p.nch / p.kSplits), chEnd = (int)((long long)(ks + 1) * p.nch / p.kSplits);
     const int mt = bid % p.mTiles; bid /= p.mTiles;
     const int xt = bid % p.xTiles; const int n = bid / p.xTiles;             // xTiles = runs of RUN flat pixels per plane
     const int o0 = mt * BM;
@@ -642,12 +648,12 @@ modconv_flat_kernel(ConvParams p) {
     const _Float16* aBase = sA + (wm * 32 + li) * AS + lh * 8;
     const _Float16* bBase = sB + (lh * NPART) * BPLANE;
 
-    fetch(0);
-    for (int ch = 0; ch < p.nch; ch++) {
+    fetch(chBegin);
+    for (int ch = chBegin; ch < chEnd; ch++) {
         __syncthreads();
         stage();
         __syncthreads();
-        if (ch + 1 < p.nch) fetch(ch + 1);
+        if (ch + 1 < chEnd) fetch(ch + 1);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int tap = 0; tap < TAPS; tap++) {
@@ -671,6 +677,22 @@ modconv_flat_kernel(ConvParams p) {
         __builtin_amdgcn_s_setprio(0);
     }
 
+    if (p.kSplits > 1) {
+        // raw partial sums, fp32, [ks][n][o][P]: the reduction applies the demodulation coefficient
+        float* pp = p.partial + ((size_t)ks * p.N + n) * p.O * P;
+        const unsigned planeF = (unsigned)P * 4u;
+        const __amdgpu_buffer_rsrc_t prr = __builtin_amdgcn_make_buffer_rsrc((void*)pp, (short)0, (int)((unsigned)p.O * planeF), 0x00020000);
+#pragma unroll
+        for (int b = 0; b < TN; b++) {
+            const unsigned base = pf[b] >= 0 ? (unsigned)oL * planeF + (unsigned)pf[b] * 4u : 0x80000000u;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float v = acc[b][r];               // a scalar first: hipcc 7.2 compiles __builtin_bit_cast of a vector ELEMENT as a read of element 0
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), prr, (int)(base + (unsigned)((r & 3) + 8 * (r >> 2)) * planeF), 0, 0);
+            }
+        }
+        return;
+    }
     // the runs are contiguous in the dense output plane: 128-byte store segments
     T* outp = (T*)p.out + (size_t)n * p.O * P;
     const unsigned planeB = (unsigned)P * (unsigned)sizeof(T);
@@ -1297,6 +1319,41 @@ static bool conv3_use_flat() {
     return v;
 }
 
+// out[n][o][f] = d[n][o] * sum_ks partial[ks][n][o][f] (ks in order: reproducible), the second half of a K-split flat convolution
+template <typename T>
+__global__ void __launch_bounds__(256)
+modconv_split_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ dcoef, T* __restrict__ out, int kSplits, long long planes, int P) {
+    const long long total = planes * P;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        float v = 0.f;
+        for (int k = 0; k < kSplits; k++) v += partial[(size_t)k * total + idx];
+        out[idx] = (T)(v * dcoef[idx / P]);
+    }
+}
+
+// CUs of the current device, read once per device
+static int conv_cu_count() {
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
+}
+
+// K splits of a flat-kernel call with `tiles` workgroups and `nch` K chunks: none when the grid gives every CU a workgroup; else up to
+// four, at least four chunks each
+static int flat_k_splits(long long tiles, int nch) {
+    static const int forced = [] { const char* e = getenv("SG3_FLAT_SPLITS"); return e ? atoi(e) : 0; }();      // A/B timing: 1 = never split
+    if (forced >= 1) return std::min(forced, std::min(4, nch));
+    const int cus = conv_cu_count();
+    if (tiles >= cus) return 1;
+    const int s = (int)std::min<long long>(std::min<long long>(4, (2LL * cus) / tiles), nch / 4);
+    return s >= 2 ? s : 1;
+}
+
 // does the patch of every RUN-pixel piece of an outH x outW plane fit FLAT_NPIX pixels?  rows touched <= (RUN - 2) / outW + 2
 static bool flat_fits(int outW, int run) { return ((run - 2) / outW + 2 + 2) * (outW + 2) <= FLAT_NPIX; }
 
@@ -1313,13 +1370,25 @@ static int launch_conv_flat(const sg3_modconv_params& q, hipStream_t st) {
     p.xTiles = ceil_div(p.outH * p.outW, RUN); p.yTiles = 1; p.mTiles = ceil_div(q.O, 64);
     const long long total = (long long)p.xTiles * p.mTiles * q.N;
     if (total > 0x7fffffffLL) { set_error("modulated_conv2d: grid too large"); return SG3_BAD_ARG; }
-    p.totalBlocks = (int)total;
     p.outPitch = p.outW; p.tailPack = 0;
+    p.kSplits = 1; p.partial = nullptr;
+    const long long planes = (long long)q.N * q.O, P = (long long)p.outH * p.outW;
+    if (q.splitScratch && q.dcoef) {
+        const int ksp = flat_k_splits(total, p.nch);
+        if (ksp > 1 && (long long)ksp * planes * P <= q.splitScratchFloats && (long long)ksp * total <= 0x7fffffffLL) { p.kSplits = ksp; p.partial = q.splitScratch; }
+    }
+    p.totalBlocks = (int)(total * p.kSplits);
     auto kern = modconv_flat_kernel<T, TN, SPLIT>;
     if (ldsBytes > 64 * 1024)
         SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), ldsBytes, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.totalBlocks), dim3(256), ldsBytes, st, p);
     SG3_LAUNCH_CHECK("modconv_flat_kernel");
+    if (p.kSplits > 1) {
+        const long long elems = planes * P;
+        const unsigned blocks = (unsigned)std::min<long long>((elems + 255) / 256, 4096);
+        hipLaunchKernelGGL((modconv_split_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float*)p.partial, q.dcoef, (T*)q.out, p.kSplits, planes, (int)P);
+        SG3_LAUNCH_CHECK("modconv_split_reduce_kernel");
+    }
     return SG3_OK;
 }
 
@@ -1456,6 +1525,18 @@ static int prep_validate(const sg3_modconv_prep_params* p) {
         SG3_REQUIRE((p->xBound > 0.f || p->xBoundDev) && p->dcoef, "modulated_conv2d_prep: f16x3 needs xBound > 0 and a dcoef buffer");
     }
     return SG3_OK;
+}
+
+int64_t sg3_modconv_split_scratch_floats(const sg3_modconv_params* p) {
+    using namespace sg3;
+    // an upper bound for the one form that splits K over workgroups (3x3, split-precision / fp16 direct kernels on narrow maps with a
+    // grid smaller than the chip): 4 partial images; 0 when the call cannot take it
+    if (!p || p->k != 3 || !p->dcoef || (p->precision != SG3_CONV_F16X3 && p->precision != SG3_CONV_F16)) return 0;
+    const long long outH = p->H + 2 * p->pad - 2, outW = p->W + 2 * p->pad - 2;
+    if (outH <= 0 || outW <= 0 || outW > 128) return 0;
+    const long long tiles = (long long)p->N * ceil_div(p->O, 64) * ceil_div((int)(outH * outW), 128);      // the smallest flat tile
+    if (tiles >= conv_cu_count() || ceil_div(p->I, 16) < 8) return 0;
+    return 4LL * p->N * p->O * outH * outW;
 }
 
 int sg3_modconv_f23_supported(int dtype, int I, int O, int H, int W, int k, int pad, int outRowStride) {

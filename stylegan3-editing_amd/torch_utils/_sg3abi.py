@@ -54,7 +54,8 @@ class BiasActParams(ctypes.Structure):
 class ModconvParams(ctypes.Structure):
     _fields_ = [('x', c_vp), ('wPacked', c_vp), ('sIn', c_vp), ('dcoef', c_vp), ('out', c_vp), ('dtype', c_i32),
                 ('N', c_i32), ('I', c_i32), ('O', c_i32), ('H', c_i32), ('W', c_i32), ('k', c_i32), ('pad', c_i32), ('precision', c_i32),
-                ('epilogueBias', c_vp), ('epilogueClamp', c_f32), ('epilogueScale', c_f32), ('outRowStride', c_i32)]
+                ('epilogueBias', c_vp), ('epilogueClamp', c_f32), ('epilogueScale', c_f32), ('outRowStride', c_i32),
+                ('splitScratch', c_vp), ('splitScratchFloats', c_i64)]
 
 
 class FourierParams(ctypes.Structure):
@@ -128,6 +129,7 @@ EXPORTS = [
     ('sg3_bias_act', ctypes.c_int, [ctypes.POINTER(BiasActParams), c_vp]),
     ('sg3_modconv_packed_floats', ctypes.c_int64, [ctypes.c_int] * 4),
     ('sg3_modulated_conv2d', ctypes.c_int, [ctypes.POINTER(ModconvParams), c_vp]),
+    ('sg3_modconv_split_scratch_floats', ctypes.c_int64, [ctypes.POINTER(ModconvParams)]),
     ('sg3_modconv_f23_supported', ctypes.c_int, [ctypes.c_int] * 8),
     ('sg3_modconv_f23_force_rows', ctypes.c_int, [ctypes.c_int]),
     ('sg3_fourier_features', ctypes.c_int, [ctypes.POINTER(FourierParams), c_vp]),

@@ -245,6 +245,10 @@ def _launch(x, w, s, demodulate, padding, input_gain, x_bound=None, x_bound_dev=
             bias, clamp, scale = epilogue
             bias = bias.detach().to(device=dev, dtype=torch.float32).contiguous()
             cp.epilogueBias, cp.epilogueClamp, cp.epilogueScale = abi.ptr(bias), float(-1.0 if clamp is None else clamp), float(scale)
+        need = int(lib.sg3_modconv_split_scratch_floats(ctypes.byref(cp)))     # > 0: a grid smaller than the chip (batch 1, small maps)
+        if need > 0:
+            scratch = torch.empty([need], dtype=torch.float32, device=dev)
+            cp.splitScratch, cp.splitScratchFloats = abi.ptr(scratch), need
         abi.check(lib.sg3_modulated_conv2d(ctypes.byref(cp), stream), 'sg3_modulated_conv2d')
     return out, pr.s_in, pr.dcoef
 
