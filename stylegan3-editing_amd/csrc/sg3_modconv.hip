@@ -1345,8 +1345,12 @@ static int conv_cu_count() {
 
 // K splits of a flat-kernel call with `tiles` workgroups and `nch` K chunks: none when the grid gives every CU a workgroup; else up to
 // four, at least four chunks each
+static int flat_forced_splits() {
+    static const int forced = [] { const char* e = getenv("SG3_FLAT_SPLITS"); return e ? atoi(e) : 0; }();      // A/B timing: 1 = never split, 2 .. 4 = always
+    return forced;
+}
 static int flat_k_splits(long long tiles, int nch) {
-    static const int forced = [] { const char* e = getenv("SG3_FLAT_SPLITS"); return e ? atoi(e) : 0; }();      // A/B timing: 1 = never split
+    const int forced = flat_forced_splits();
     if (forced >= 1) return std::min(forced, std::min(4, nch));
     const int cus = conv_cu_count();
     if (tiles >= cus) return 1;
@@ -1535,7 +1539,7 @@ int64_t sg3_modconv_split_scratch_floats(const sg3_modconv_params* p) {
     const long long outH = p->H + 2 * p->pad - 2, outW = p->W + 2 * p->pad - 2;
     if (outH <= 0 || outW <= 0 || outW > 128) return 0;
     const long long tiles = (long long)p->N * ceil_div(p->O, 64) * ceil_div((int)(outH * outW), 128);      // the smallest flat tile
-    if (tiles >= conv_cu_count() || ceil_div(p->I, 16) < 8) return 0;
+    if (flat_forced_splits() < 2 && (tiles >= conv_cu_count() || ceil_div(p->I, 16) < 8)) return 0;
     return 4LL * p->N * p->O * outH * outW;
 }
 
