@@ -33,3 +33,18 @@ def test_last_forward_groups_launches_by_layer():
     assert [len(g[1]) for g in groups] == [2 if j in (6, 8) else 1 for j in range(14)]
     assert all(i >= first_of_last for _, ids in groups for i in ids)          # nothing of the warm-up forward
     assert sum(len(ids) for _, ids in groups) == 16
+
+
+def test_committed_traffic_files_belong_to_the_current_kernel_source():
+    """bench.py quotes `roofline.traffic` / `inversion.roofline.traffic` from profiles/flrelu_traffic*.json only when their stamp matches
+    csrc/sg3_filtered_lrelu.hip; a source edit silently turns both fields into null.  This test is the reminder to re-collect
+    (gpurun -- 'bash tools/collect_traffic.sh', then copy the two files into profiles/)."""
+    import hashlib
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, 'stylegan3-editing_amd', 'csrc', 'sg3_filtered_lrelu.hip'), 'rb') as f:
+        sha = hashlib.sha256(f.read()).hexdigest()[:16]
+    for name in ('flrelu_traffic.json', 'flrelu_traffic_R.json'):
+        with open(os.path.join(root, 'profiles', name)) as f:
+            assert json.load(f)['kernel_source_sha'] == sha, f'profiles/{name} was collected on another version of the kernel source'
