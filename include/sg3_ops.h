@@ -405,8 +405,9 @@ typedef struct sg3_modconv_params {
      * bytes and hand the [..., :outW] view on: a 1046-float row is 4184 bytes, so every 128-byte store segment of a dense output
      * straddles two cache lines (3x3 split-precision / fp16 kernels only; other forms require 0 or outW). */
     int32_t        outRowStride;
-    /* Optional scratch for small grids (batch 1 on the 36^2 .. 84^2 maps: fewer tiles than CUs): the 3x3 direct kernel then splits
-     * the input channels of a tile over up to four workgroups and a second launch adds their partial sums in order.  NULL / too
+    /* Optional scratch for small grids (batch 1 on the 36^2 .. 84^2 maps: fewer tiles than CUs): the 3x3 direct kernel and the 1x1
+     * GEMM kernel (fp32 tensors) then split the input channels of a tile over up to four workgroups and a second launch adds their
+     * partial sums in order.  NULL / too
      * small = no split (same result up to fp32 summation order).  sg3_modconv_split_scratch_floats gives a sufficient size. */
     float*         splitScratch;
     int64_t        splitScratchFloats;

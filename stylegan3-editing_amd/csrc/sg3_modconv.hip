@@ -758,6 +758,10 @@ modconv1_f16x3_kernel(ConvParams p) {
         const int nb = p.totalBlocks, q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
+    // grids smaller than the chip: the K stages of a tile split over kSplits workgroups, each writing its share (demodulation
+    // applied: the epilogue is linear) to its own fp32 image partial[ks]; modconv_split_reduce_kernel adds the images in order
+    const int ks = bid % p.kSplits; bid /= p.kSplits;
+    const int chBegin = (int)((long long)ks * p.nch / p.kSplits), chEnd = (int)((long long)(ks + 1) * p.nch / p.kSplits);
     const int mt = bid % p.mTiles; bid /= p.mTiles;
     const int xt = bid % p.xTiles; bid /= p.xTiles;
     const int yt = bid % p.yTiles; const int n = bid / p.yTiles;
@@ -914,12 +918,12 @@ modconv1_f16x3_kernel(ConvParams p) {
             }
     };
 
-    fetch(0);
-    stage(smh, 0);
+    fetch(chBegin);
+    stage(smh + (NBUF == 2 ? (chBegin & 1) * BUF : 0), chBegin);
     __syncthreads();
-    for (int ch = 0; ch < p.nch; ch++) {
+    for (int ch = chBegin; ch < chEnd; ch++) {
         const _Float16* cur = smh + (NBUF == 2 ? (ch & 1) * BUF : 0);
-        const bool more = ch + 1 < p.nch;
+        const bool more = ch + 1 < chEnd;
         if (more) fetch(ch + 1);
         if (M16) {
             stage_m16(cur);
@@ -947,7 +951,8 @@ modconv1_f16x3_kernel(ConvParams p) {
         }
     }
 
-    T* outp = (T*)p.out + (size_t)n * p.O * P;
+    // (a K-split call has T = float: its partial images are fp32)
+    T* outp = (p.kSplits > 1 ? (T*)p.partial + (size_t)ks * p.N * p.O * P : (T*)p.out) + (size_t)n * p.O * P;
     if (M16) {
         // accumulator register (rb * 2 + pb) * 4 + i of block (a, b): channel (wm TM + a) 32 + rb 16 + 4 lg + i, pixel (wn TN + b) 32 + pb 16 + l16
         const unsigned planeB16 = (unsigned)P * (unsigned)sizeof(T);
@@ -1319,7 +1324,8 @@ static bool conv3_use_flat() {
     return v;
 }
 
-// out[n][o][f] = d[n][o] * sum_ks partial[ks][n][o][f] (ks in order: reproducible), the second half of a K-split flat convolution
+// out[n][o][f] = d[n][o] * sum_ks partial[ks][n][o][f] (ks in order: reproducible; d = 1 when dcoef is null: the 1x1 kernel applies it
+// before storing its partial image), the second half of a K-split convolution
 template <typename T>
 __global__ void __launch_bounds__(256)
 modconv_split_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ dcoef, T* __restrict__ out, int kSplits, long long planes, int P) {
@@ -1327,7 +1333,7 @@ modconv_split_reduce_kernel(const float* __restrict__ partial, const float* __re
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         float v = 0.f;
         for (int k = 0; k < kSplits; k++) v += partial[(size_t)k * total + idx];
-        out[idx] = (T)(v * dcoef[idx / P]);
+        out[idx] = (T)(dcoef ? v * dcoef[idx / P] : v);
     }
 }
 
@@ -1470,15 +1476,27 @@ static int launch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     p.xTiles = ceil_div(q.H * q.W, ROWS * 32); p.yTiles = 1; p.mTiles = ceil_div(q.O, BM);     // flat 256-pixel tiles
     const long long total = (long long)p.xTiles * p.yTiles * p.mTiles * q.N;
     if (total > 0x7fffffffLL) { set_error("modulated_conv2d: grid too large"); return SG3_BAD_ARG; }
-    p.totalBlocks = (int)total;
+    p.kSplits = 1; p.partial = nullptr;
+    if (q.splitScratch && std::is_same<T, float>::value) {
+        const int ksp = flat_k_splits(total, p.nch);
+        const long long elems = (long long)q.N * q.O * q.H * q.W;
+        if (ksp > 1 && (long long)ksp * elems <= q.splitScratchFloats && (long long)ksp * total <= 0x7fffffffLL) { p.kSplits = ksp; p.partial = q.splitScratch; }
+    }
+    p.totalBlocks = (int)(total * p.kSplits);
     // the 16x16x32 form for the compute-bound tiles (R-1024, batch 8: 28.4 vs 32.2 ms over the 1024 .. 406-channel layers); the
     // thin HBM-bound layers keep 32x32x16: its stores are 128-byte row segments, the 16-wide blocks' 64-byte ones cost them 5 %
     const bool m16 = NBUF == 2 && conv1_use_m16();
     auto kern = m16 ? modconv1_f16x3_kernel<T, WM, WN, TM, TN, SPLIT, NBUF, true> : modconv1_f16x3_kernel<T, WM, WN, TM, TN, SPLIT, NBUF, false>;
     if (ldsBytes > 64 * 1024)
         SG3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), ldsBytes, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.totalBlocks), dim3(512), ldsBytes, st, p);
     SG3_LAUNCH_CHECK("modconv1_f16x3_kernel");
+    if (p.kSplits > 1) {
+        const long long planes = (long long)q.N * q.O, P = (long long)q.H * q.W, elems = planes * P;
+        const unsigned blocks = (unsigned)std::min<long long>((elems + 255) / 256, 4096);
+        hipLaunchKernelGGL((modconv_split_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float*)p.partial, (const float*)nullptr, (T*)q.out, p.kSplits, planes, (int)P);
+        SG3_LAUNCH_CHECK("modconv_split_reduce_kernel");
+    }
     return SG3_OK;
 }
 
@@ -1535,7 +1553,16 @@ int64_t sg3_modconv_split_scratch_floats(const sg3_modconv_params* p) {
     using namespace sg3;
     // an upper bound for the one form that splits K over workgroups (3x3, split-precision / fp16 direct kernels on narrow maps with a
     // grid smaller than the chip): 4 partial images; 0 when the call cannot take it
-    if (!p || p->k != 3 || !p->dcoef || (p->precision != SG3_CONV_F16X3 && p->precision != SG3_CONV_F16)) return 0;
+    if (!p || (p->precision != SG3_CONV_F16X3 && p->precision != SG3_CONV_F16)) return 0;
+    if (p->k == 1) {
+        // the 1x1 GEMM kernel (config R): fp32 tensors, 256-pixel tiles x up to 256 rows; its stages are 32 channels
+        if (p->dtype != SG3_F32 || p->pad != 0 || p->O <= 4) return 0;
+        const long long P1 = (long long)p->H * p->W;
+        const long long tiles1 = (long long)p->N * ceil_div(p->O, 256) * ceil_div((int)std::min<long long>(P1, 0x7fffffff), 256);
+        if (flat_forced_splits() < 2 && (tiles1 >= conv_cu_count() || ceil_div(p->I, 32) < 8)) return 0;
+        return 4LL * p->N * p->O * P1;
+    }
+    if (p->k != 3 || !p->dcoef) return 0;
     const long long outH = p->H + 2 * p->pad - 2, outW = p->W + 2 * p->pad - 2;
     if (outH <= 0 || outW <= 0 || outW > 128) return 0;
     const long long tiles = (long long)p->N * ceil_div(p->O, 64) * ceil_div((int)(outH * outW), 128);      // the smallest flat tile

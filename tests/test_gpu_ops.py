@@ -898,14 +898,14 @@ def test_known_amax_reaches_the_modulated_convolution_backward_and_changes_nothi
         assert torch.equal(a, c)
 
 
-@pytest.mark.parametrize('n,ci,co,h', [(1, 512, 512, 36), (2, 256, 130, 50), (1, 512, 512, 52)])
-def test_modulated_conv2d_k_split_on_small_grids_matches_the_unsplit_kernel(n, ci, co, h):
-    """Fewer tiles than CUs (batch 1 on the small maps, PTI): the direct 3x3 kernel splits the input channels of a tile over up to four
+@pytest.mark.parametrize('n,ci,co,h,k', [(1, 512, 512, 36, 3), (2, 256, 130, 50, 3), (1, 512, 512, 52, 3), (1, 1024, 1024, 36, 1), (2, 645, 406, 40, 1)])
+def test_modulated_conv2d_k_split_on_small_grids_matches_the_unsplit_kernel(n, ci, co, h, k):
+    """Fewer tiles than CUs (batch 1 on the small maps, PTI): the direct 3x3 kernel and the 1x1 GEMM kernel split the input channels of a tile over up to four
     workgroups (sg3_modconv_params.splitScratch) and a second launch adds the partial sums.  Against the same call without scratch
     (one workgroup per tile walks all chunks) and against float64."""
     from torch_utils import _sg3abi
     from torch_utils.ops import modulated_conv as mc
-    x, w, s = T(rand(1, n, ci, h, h)), T(rand(2, co, ci, 3, 3)), T(rand(3, n, ci) + 1.5)
+    x, w, s = T(rand(1, n, ci, h, h)), T(rand(2, co, ci, k, k)), T(rand(3, n, ci) + 1.5)
     lib = _sg3abi.load()
 
     class _NoScratch:                                   # the library with the scratch query answering 0: the caller then passes none
@@ -915,16 +915,16 @@ def test_modulated_conv2d_k_split_on_small_grids_matches_the_unsplit_kernel(n, c
             return getattr(lib, name)
 
     with torch.no_grad():
-        split = mc.modulated_conv2d(x=x, w=w, s=s, padding=2, demodulate=True, x_bound=float(x.abs().max()) * 1.01)
+        split = mc.modulated_conv2d(x=x, w=w, s=s, padding=k - 1, demodulate=True, x_bound=float(x.abs().max()) * 1.01)
         saved = _sg3abi._lib
         _sg3abi._lib = _NoScratch()
         try:
-            plain = mc.modulated_conv2d(x=x, w=w, s=s, padding=2, demodulate=True, x_bound=float(x.abs().max()) * 1.01)
+            plain = mc.modulated_conv2d(x=x, w=w, s=s, padding=k - 1, demodulate=True, x_bound=float(x.abs().max()) * 1.01)
         finally:
             _sg3abi._lib = saved
-    ref = mc._composite(x.double(), w.double(), s.double(), True, 2, None)
+    ref = mc._composite(x.double(), w.double(), s.double(), True, k - 1, None)
     scale = float(ref.abs().max())
     assert float((split.double() - ref).abs().max()) <= 2e-6 * scale and float((plain.double() - ref).abs().max()) <= 3e-6 * scale
     assert float((split - plain).abs().max()) <= 4e-6 * scale          # two fp32 summation orders over K = 9 I
-    if (n, ci, co, h) == (1, 512, 512, 36):                             # L0 - L2 of a batch-1 PTI step: flat kernel, 96 tiles, four splits
+    if (n, ci, co, h) in ((1, 512, 512, 36), (1, 1024, 1024, 36)):      # L0 - L2 of a batch-1 PTI step (T: flat kernel, 96 tiles; R: 1x1 GEMM, 24 tiles): four splits
         assert not torch.equal(split, plain)                            # the split path did run
