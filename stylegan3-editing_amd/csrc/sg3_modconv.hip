@@ -1478,7 +1478,9 @@ static int launch_conv1_f16x3(const sg3_modconv_params& q, hipStream_t st) {
     if (total > 0x7fffffffLL) { set_error("modulated_conv2d: grid too large"); return SG3_BAD_ARG; }
     p.kSplits = 1; p.partial = nullptr;
     if (q.splitScratch && std::is_same<T, float>::value) {
-        const int ksp = flat_k_splits(total, p.nch);
+        // this kernel's workgroups are eight waves with two resident per CU: measured neutral from ~100 tiles up (R-1024 batch 4: 15.1 vs
+        // 15.0 ms), +1.7 % at 48, +5.6 % at 24 -- so it splits below a quarter of a tile per CU
+        const int ksp = flat_k_splits(4 * total, p.nch);
         const long long elems = (long long)q.N * q.O * q.H * q.W;
         if (ksp > 1 && (long long)ksp * elems <= q.splitScratchFloats && (long long)ksp * total <= 0x7fffffffLL) { p.kSplits = ksp; p.partial = q.splitScratch; }
     }
@@ -1559,7 +1561,7 @@ int64_t sg3_modconv_split_scratch_floats(const sg3_modconv_params* p) {
         if (p->dtype != SG3_F32 || p->pad != 0 || p->O <= 4) return 0;
         const long long P1 = (long long)p->H * p->W;
         const long long tiles1 = (long long)p->N * ceil_div(p->O, 256) * ceil_div((int)std::min<long long>(P1, 0x7fffffff), 256);
-        if (flat_forced_splits() < 2 && (tiles1 >= conv_cu_count() || ceil_div(p->I, 32) < 8)) return 0;
+        if (flat_forced_splits() < 2 && (4 * tiles1 >= conv_cu_count() || ceil_div(p->I, 32) < 8)) return 0;
         return 4LL * p->N * p->O * P1;
     }
     if (p->k != 3 || !p->dcoef) return 0;
